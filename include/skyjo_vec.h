@@ -1,0 +1,204 @@
+/*
+ * skyjo_vec.h - C ABI of the MI355X-native vectorised SkyJo environment (libskyjo_vec.so).
+ *
+ * This is the drop-in boundary for ONE hot path of michaelfeil/skyjo_rl: the SkyJo state transition
+ * plus observation / action-mask build.  The reference has no FFI: the path sits behind two Python
+ * classes, so every entry point below cites the Python interface it replaces
+ * (paths relative to the reference checkout):
+ *
+ *   SkyjoGame.__init__ / reset / set_seed      rlskyjo/game/skyjo.py:20-49, 52-74, 84-94
+ *   SkyjoGame.collect_observation              rlskyjo/game/skyjo.py:148-199 (+ helpers :201-302)
+ *   SkyjoGame.act                              rlskyjo/game/skyjo.py:308-335 (+ :337-498)
+ *   SkyjoGame.get_game_metrics/expected_action rlskyjo/game/skyjo.py:500-504
+ *   SimpleSkyjoEnv.step / reset / seed         rlskyjo/environment/skyjo_env.py:216-252, 254-267, 280-290
+ *   SimpleSkyjoEnv._calc_final_rewards         rlskyjo/environment/skyjo_env.py:293-312
+ *   TerminateIllegalWrapper(illegal_reward=-1) rlskyjo/environment/skyjo_env.py:23
+ *
+ * All games of a handle share one configuration and live on ONE GPU in an LDS-friendly tiled
+ * structure-of-arrays layout.  Unless a parameter is named *_host, data pointers are
+ * DEVICE pointers (e.g. torch tensor .data_ptr()); buffers are caller-owned, the handle owns its
+ * state.  `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls on one
+ * handle must be serialised by the caller; every call is asynchronous on `stream` unless it has a
+ * host output.  Return value: 0 = ok, negative = SKYJO_E_*; skyjo_vec_last_error() describes the
+ * last failure on the calling thread.  Game-level illegal actions are data (status byte), never
+ * errors.  There is NO CPU fallback: without a gfx950 device skyjo_vec_create fails.
+ */
+#ifndef SKYJO_VEC_H
+#define SKYJO_VEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKYJO_ABI_VERSION 1
+#define SKYJO_MAX_PLAYERS 12 /* skyjo.py:24-26 */
+#define SKYJO_NUM_ACTIONS 26 /* skyjo.py:46 */
+#define SKYJO_NUM_CARDS 150  /* skyjo.py:80 */
+#define SKYJO_HAND_NONE 15   /* skyjo.py:33 */
+#define SKYJO_REFUNDED (-14) /* skyjo.py:34 */
+
+/* error codes */
+#define SKYJO_OK 0
+#define SKYJO_E_INVALID (-1) /* bad argument / handle */
+#define SKYJO_E_DEVICE (-2)  /* HIP runtime error (text in last_error) */
+#define SKYJO_E_NOGPU (-3)   /* no usable gfx950 device */
+#define SKYJO_E_STATE (-4)   /* call not valid in the current state (e.g. step before seed) */
+
+/* per-game status byte of the last step */
+#define SKYJO_ST_OK 0        /* action applied */
+#define SKYJO_ST_ILLEGAL 1   /* action masked out or out of range: TerminateIllegalWrapper semantics */
+#define SKYJO_ST_NOOP_DONE 2 /* game already over and auto_reset off (skyjo.py:316-321) */
+#define SKYJO_ST_RESET 3     /* game was over: a new episode was dealt, the action was ignored */
+#define SKYJO_ST_WAIT 4      /* game over, next deal not ready yet (only with deferred dealing) */
+
+/* RNG modes */
+#define SKYJO_RNG_MT19937 0 /* numpy legacy stream, bit-identical deals to the reference */
+#define SKYJO_RNG_PHILOX 1  /* counter-based Philox4x32-10 sessions, same shuffle algorithm */
+
+typedef struct skyjo_vec skyjo_vec; /* opaque */
+
+typedef struct skyjo_vec_config {
+  int32_t abi_version;      /* SKYJO_ABI_VERSION */
+  int32_t num_envs;         /* parallel games on this device */
+  int32_t num_players;      /* 1..12                       (skyjo.py:21) */
+  int32_t observe_indirect; /* observe_other_player_indirect (skyjo.py:42-45) */
+  double score_penalty;     /* skyjo.py:21,496-497 */
+  double mean_reward;       /* skyjo_env.py:43,308 */
+  double reward_refunded;   /* skyjo_env.py:44,310-311 */
+  double illegal_reward;    /* skyjo_env.py:23 (-1) */
+  int32_t device_id;        /* HIP device ordinal */
+  int32_t rng_mode;         /* SKYJO_RNG_* */
+  int32_t auto_reset;       /* 1: a finished game is re-dealt by the next step */
+  int32_t reserved;
+  uint64_t game_id0;        /* global id of local game 0 (multi-GPU shards; seeds and policy keys use it) */
+} skyjo_vec_config;
+
+/* Output record: one per game per step, `record_bytes` long (64 for the indirect observation):
+ *   [0, D)            int8 observations            (skyjo.py:180-190)
+ *   [Dp, Dp+26)       int8 action_mask, Dp = (D+3)&~3 (skyjo.py:201-224)
+ *   [Dp+26]           expected player (agent id)   (skyjo.py:503)
+ *   [Dp+27]           phase 0 = draw, 1 = place
+ *   [Dp+28]           done                         (skyjo_env.py:247)
+ *   [Dp+29]           status SKYJO_ST_*
+ *   [Dp+30, Dp+32)    uint16 steps in this episode */
+typedef struct skyjo_vec_info {
+  int32_t num_envs, num_players, obs_dim, record_bytes;
+  int32_t mask_offset, meta_offset, state_bytes, tile_games;
+} skyjo_vec_info;
+
+typedef struct skyjo_vec_counters {
+  uint64_t steps;    /* applied actions incl. the consumed terminal draw */
+  uint64_t episodes; /* games that reached their natural end */
+  uint64_t illegal;  /* games ended by an illegal action */
+  uint64_t resets;   /* deals consumed */
+  uint64_t sum_len;  /* sum of episode lengths of finished episodes */
+  uint64_t reshuffles;
+  uint64_t iters;    /* lockstep iterations executed */
+  uint64_t waits;
+  double sum_score[SKYJO_MAX_PLAYERS];  /* per seat, finished episodes */
+  double sum_reward[SKYJO_MAX_PLAYERS]; /* per seat, finished + illegal episodes */
+} skyjo_vec_counters;
+
+/* Canonical per-game state (debug, fixtures, snapshot/restore).  Field names follow skyjo.py. */
+typedef struct skyjo_game_state {
+  int8_t players_cards[SKYJO_MAX_PLAYERS][12];  /* skyjo.py:63 */
+  int8_t players_masked[SKYJO_MAX_PLAYERS][12]; /* skyjo.py:72, 0 refunded / 1 open / 2 hidden */
+  int8_t drawpile[SKYJO_NUM_CARDS];             /* pop from the end, skyjo.py:366 */
+  int8_t discard_pile[SKYJO_NUM_CARDS];         /* push/pop at the end, skyjo.py:370,393 */
+  int16_t n_draw, n_disc;
+  int8_t hand_card;        /* 15 = none */
+  uint8_t expected_player; /* skyjo.py:144 */
+  uint8_t expected_phase;  /* 0 draw / 1 place */
+  uint8_t is_terminated;   /* skyjo.py:54 */
+  uint8_t done;            /* env-level: terminated or ended by illegal action */
+  uint8_t status;
+  uint16_t episode_steps;
+  uint32_t episode;        /* deals since seeding, 0 = the deal made by seed() */
+  uint32_t reshuffles;
+  int32_t num_refunded[SKYJO_MAX_PLAYERS]; /* skyjo.py:57 */
+  int32_t num_placed[SKYJO_MAX_PLAYERS];   /* skyjo.py:58 */
+  double final_score[SKYJO_MAX_PLAYERS];   /* skyjo.py:59, valid when is_terminated */
+  double rewards[SKYJO_MAX_PLAYERS];       /* skyjo_env.py:244, valid when done */
+} skyjo_game_state;
+
+const char *skyjo_vec_last_error(void);
+int skyjo_vec_abi_version(void);
+
+/* SkyjoGame.__init__ + SimpleSkyjoEnv.__init__ (skyjo.py:20-49, skyjo_env.py:38-153) for num_envs games.
+ * Unlike the reference no cards are dealt until skyjo_vec_seed. */
+int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out);
+int skyjo_vec_destroy(skyjo_vec *h);
+int skyjo_vec_get_info(const skyjo_vec *h, skyjo_vec_info *out);
+
+/* SkyjoGame.set_seed (skyjo.py:84-88) per game: game i is seeded with seeds_host[i], or with
+ * base_seed + game_id0 + i when seeds_host is NULL; the legacy stream is seeded with value+1 and
+ * the first deal is made immediately, exactly like set_seed.  Must precede every other call. */
+int skyjo_vec_seed(skyjo_vec *h, const uint64_t *seeds_host, uint64_t base_seed, void *stream);
+
+/* SkyjoGame.reset / SimpleSkyjoEnv.reset (skyjo.py:52-74, skyjo_env.py:254-267) for the games whose
+ * mask byte is non-zero (all when mask is NULL).  records_out (may be NULL): [num_envs][record_bytes]. */
+int skyjo_vec_reset(skyjo_vec *h, const uint8_t *mask, void *records_out, void *stream);
+
+/* SimpleSkyjoEnv.step (skyjo_env.py:216-252) = SkyjoGame.act (skyjo.py:308-335) for the expected player
+ * of every game, then the observation of the next expected player.  actions: int32[num_envs]. */
+int skyjo_vec_step(skyjo_vec *h, const int32_t *actions, void *records_out, void *stream);
+
+/* `iters` lockstep iterations in one launch with the uniform random admissible policy
+ * (rlskyjo/models/random_admissible_policy.py:6-28) evaluated on device.
+ * records_out: NULL, or [iters][num_envs][record_bytes] (record AFTER each iteration);
+ * actions_out: NULL, or int32[iters][num_envs] (-1 where no action was applied). */
+int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *records_out, int32_t *actions_out,
+                      void *stream);
+
+/* SimpleSkyjoEnv.observe (skyjo_env.py:199-214) = collect_observation(player) (skyjo.py:148-199) without
+ * changing state.  players: int32[num_envs] or NULL for the expected player of each game. */
+int skyjo_vec_observe(skyjo_vec *h, const int32_t *players, void *records_out, void *stream);
+
+/* Split records into the reference's dense arrays: obs int8[n][D], mask int8[n][26]; any output may be NULL. */
+int skyjo_vec_unpack(skyjo_vec *h, const void *records, int64_t n_records, int8_t *obs, int8_t *mask,
+                     uint8_t *agent, uint8_t *phase, uint8_t *done, uint8_t *status, void *stream);
+
+/* rewards double[num_envs][num_players] (skyjo_env.py:293-312; valid where done), device pointers owned by h */
+const double *skyjo_vec_rewards_ptr(const skyjo_vec *h);
+const double *skyjo_vec_scores_ptr(const skyjo_vec *h);
+const uint8_t *skyjo_vec_done_ptr(const skyjo_vec *h);
+
+/* synchronising host-side accessors */
+int skyjo_vec_get_counters(skyjo_vec *h, skyjo_vec_counters *out_host, void *stream);
+int skyjo_vec_reset_counters(skyjo_vec *h, void *stream);
+int skyjo_vec_get_state(skyjo_vec *h, int32_t game, skyjo_game_state *out_host, void *stream);
+int skyjo_vec_set_state(skyjo_vec *h, int32_t game, const skyjo_game_state *in_host, void *stream);
+/* np.random.seed(value) on one game's legacy stream without dealing (fixture injection) */
+int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream);
+
+/* Per-launch timing with HIP events recorded on the launch stream.  Returns and clears what was collected
+ * since the last call (sum of milliseconds and launch counts of the step/rollout kernel and of the dealing
+ * kernel), then switches collection on/off.  Synchronises the device. */
+int skyjo_vec_profile(skyjo_vec *h, int enable, double *step_ms, int64_t *step_launches, double *deal_ms,
+                      int64_t *deal_launches);
+
+/* Tunables.  SKYJO_OPT_DEAL_INTERVAL: skyjo_vec_step launches between two runs of the dealing kernel
+ * (1..64, default 1); a finished game whose next deal is not ready yet reports SKYJO_ST_WAIT. */
+#define SKYJO_OPT_DEAL_INTERVAL 1
+int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value);
+
+/* host-pointer conveniences for small batches (single-game AEC view): synchronous */
+int skyjo_vec_step_host(skyjo_vec *h, const int32_t *actions_host, void *records_out_host);
+int skyjo_vec_observe_host(skyjo_vec *h, const int32_t *players_host, void *records_out_host);
+int skyjo_vec_reset_host(skyjo_vec *h, const uint8_t *mask_host, void *records_out_host);
+int skyjo_vec_get_rewards_host(skyjo_vec *h, double *rewards_out_host, double *scores_out_host,
+                               uint8_t *done_out_host);
+
+/* plain device-memory helpers so that a caller without torch can own buffers */
+int skyjo_dev_malloc(int device_id, size_t bytes, void **out);
+int skyjo_dev_free(void *p);
+int skyjo_dev_copy(void *dst, const void *src, size_t bytes, int kind /*1 h2d, 2 d2h, 3 d2d*/, void *stream);
+int skyjo_dev_sync(void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKYJO_VEC_H */

@@ -1,0 +1,115 @@
+"""ctypes loader for libskyjo_vec.so (the HIP / gfx950 engine).
+
+The product has no CPU path: when the shared library is missing, cannot be loaded, or finds no
+gfx950 device, every entry point raises.  Signatures mirror include/skyjo_vec.h.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libskyjo_vec.so")
+
+ABI_VERSION = 1
+MAX_PLAYERS = 12
+ST_OK, ST_ILLEGAL, ST_NOOP_DONE, ST_RESET, ST_WAIT = 0, 1, 2, 3, 4
+RNG_MT19937, RNG_PHILOX = 0, 1
+
+
+class SkyjoNativeError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("num_envs", C.c_int32), ("num_players", C.c_int32),
+                ("observe_indirect", C.c_int32), ("score_penalty", C.c_double), ("mean_reward", C.c_double),
+                ("reward_refunded", C.c_double), ("illegal_reward", C.c_double), ("device_id", C.c_int32),
+                ("rng_mode", C.c_int32), ("auto_reset", C.c_int32), ("reserved", C.c_int32),
+                ("game_id0", C.c_uint64)]
+
+
+class Info(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("num_envs", "num_players", "obs_dim", "record_bytes", "mask_offset",
+                                          "meta_offset", "state_bytes", "tile_games")]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("steps", "episodes", "illegal", "resets", "sum_len", "reshuffles",
+                                           "iters", "waits")] + [
+        ("sum_score", C.c_double * MAX_PLAYERS), ("sum_reward", C.c_double * MAX_PLAYERS)]
+
+
+class GameState(C.Structure):
+    _fields_ = [("players_cards", (C.c_int8 * 12) * MAX_PLAYERS), ("players_masked", (C.c_int8 * 12) * MAX_PLAYERS),
+                ("drawpile", C.c_int8 * 150), ("discard_pile", C.c_int8 * 150), ("n_draw", C.c_int16),
+                ("n_disc", C.c_int16), ("hand_card", C.c_int8), ("expected_player", C.c_uint8),
+                ("expected_phase", C.c_uint8), ("is_terminated", C.c_uint8), ("done", C.c_uint8),
+                ("status", C.c_uint8), ("episode_steps", C.c_uint16), ("episode", C.c_uint32),
+                ("reshuffles", C.c_uint32), ("num_refunded", C.c_int32 * MAX_PLAYERS),
+                ("num_placed", C.c_int32 * MAX_PLAYERS), ("final_score", C.c_double * MAX_PLAYERS),
+                ("rewards", C.c_double * MAX_PLAYERS)]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_capi_symbols.py checks against the header
+VP, I32, I64, U64, U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32
+SIGNATURES = {
+    "skyjo_vec_last_error": (C.c_char_p, []),
+    "skyjo_vec_abi_version": (C.c_int, []),
+    "skyjo_vec_create": (C.c_int, [C.POINTER(Config), C.POINTER(VP)]),
+    "skyjo_vec_destroy": (C.c_int, [VP]),
+    "skyjo_vec_get_info": (C.c_int, [VP, C.POINTER(Info)]),
+    "skyjo_vec_seed": (C.c_int, [VP, VP, U64, VP]),
+    "skyjo_vec_reset": (C.c_int, [VP, VP, VP, VP]),
+    "skyjo_vec_step": (C.c_int, [VP, VP, VP, VP]),
+    "skyjo_vec_rollout": (C.c_int, [VP, I32, U64, VP, VP, VP]),
+    "skyjo_vec_observe": (C.c_int, [VP, VP, VP, VP]),
+    "skyjo_vec_unpack": (C.c_int, [VP, VP, I64, VP, VP, VP, VP, VP, VP, VP]),
+    "skyjo_vec_rewards_ptr": (VP, [VP]),
+    "skyjo_vec_scores_ptr": (VP, [VP]),
+    "skyjo_vec_done_ptr": (VP, [VP]),
+    "skyjo_vec_get_counters": (C.c_int, [VP, C.POINTER(Counters), VP]),
+    "skyjo_vec_reset_counters": (C.c_int, [VP, VP]),
+    "skyjo_vec_get_state": (C.c_int, [VP, I32, C.POINTER(GameState), VP]),
+    "skyjo_vec_set_state": (C.c_int, [VP, I32, C.POINTER(GameState), VP]),
+    "skyjo_vec_seed_raw": (C.c_int, [VP, I32, U32, VP]),
+    "skyjo_vec_profile": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(I64), C.POINTER(C.c_double),
+                                    C.POINTER(I64)]),
+    "skyjo_vec_set_option": (C.c_int, [VP, C.c_int, I64]),
+    "skyjo_vec_step_host": (C.c_int, [VP, VP, VP]),
+    "skyjo_vec_observe_host": (C.c_int, [VP, VP, VP]),
+    "skyjo_vec_reset_host": (C.c_int, [VP, VP, VP]),
+    "skyjo_vec_get_rewards_host": (C.c_int, [VP, VP, VP, VP]),
+    "skyjo_dev_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(VP)]),
+    "skyjo_dev_free": (C.c_int, [VP]),
+    "skyjo_dev_copy": (C.c_int, [VP, VP, C.c_size_t, C.c_int, VP]),
+    "skyjo_dev_sync": (C.c_int, [VP]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP engine or raise SkyjoNativeError - never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SkyjoNativeError(
+            f"{LIB_PATH} is missing: build it with `python -m skyjo_rl_amd.build` (hipcc, gfx950). "
+            "skyjo_rl_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise SkyjoNativeError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.skyjo_vec_abi_version() != ABI_VERSION:
+        raise SkyjoNativeError("libskyjo_vec.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().skyjo_vec_last_error()
+        raise SkyjoNativeError(f"libskyjo_vec error {rc}: {msg.decode() if msg else ''}")

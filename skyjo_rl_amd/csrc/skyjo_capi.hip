@@ -1,0 +1,556 @@
+// skyjo_capi.hip - host side of libskyjo_vec.so: the extern "C" boundary declared in
+// include/skyjo_vec.h, handle / memory management and kernel launches.  gfx950 only, no CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "skyjo_device.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(SKYJO_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+  } while (0)
+
+constexpr int kMaxRolloutChunk = 16;  // iterations per launch: shorter than any episode, so a game
+                                      // never needs two fresh deals inside one launch
+
+}  // namespace
+
+struct skyjo_vec {
+  skyjo_vec_config cfg{};
+  SkParams P{};
+  size_t G = 0;           // tiles * 64
+  size_t lds_bytes = 0;
+  bool seeded = false;
+  int list_sel = 0;
+  int pending_deals = 0;  // step launches since the refill list was last drained
+  int deal_interval = 1;
+  uint64_t iter = 0;
+  // lazily allocated scratch for the *_host conveniences
+  int32_t *d_actions = nullptr;
+  uint8_t *d_records = nullptr;
+  uint8_t *d_mask = nullptr;
+  std::vector<void *> allocs;
+  // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_step, ev_deal;
+};
+
+namespace {
+
+template <class T>
+int dalloc(skyjo_vec *h, T **out, size_t count, bool zero = true) {
+  void *p = nullptr;
+  HIPCHK(hipMalloc(&p, count * sizeof(T)));
+  if (zero) HIPCHK(hipMemset(p, 0, count * sizeof(T)));
+  h->allocs.push_back(p);
+  *out = (T *)p;
+  return SKYJO_OK;
+}
+
+int prof_begin(skyjo_vec *h, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, hipStream_t s) {
+  if (!h->profile) return SKYJO_OK;
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a));
+  HIPCHK(hipEventCreate(&b));
+  HIPCHK(hipEventRecord(a, s));
+  v.emplace_back(a, b);
+  return SKYJO_OK;
+}
+
+int prof_end(skyjo_vec *h, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, hipStream_t s) {
+  if (!h->profile) return SKYJO_OK;
+  HIPCHK(hipEventRecord(v.back().second, s));
+  return SKYJO_OK;
+}
+
+int launch_deal(skyjo_vec *h, hipStream_t s, bool all) {
+  int blocks = (int)(h->G / SK_TILE);
+  if (blocks > 512) blocks = 512;
+  int rc;
+  if ((rc = prof_begin(h, h->ev_deal, s))) return rc;
+  hipLaunchKernelGGL(k_deal, dim3(blocks), dim3(SK_TILE), h->lds_bytes, s, h->P, h->list_sel, all ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  if ((rc = prof_end(h, h->ev_deal, s))) return rc;
+  if (!all) h->list_sel ^= 1;
+  h->pending_deals = 0;
+  return SKYJO_OK;
+}
+
+int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions, uint8_t *rec, int32_t *act_out,
+                int iters, uint64_t policy_seed) {
+  dim3 grid(h->P.tiles), block(SK_TILE);
+  const bool ind = h->P.L.indirect != 0;
+#define LAUNCH(I, Pol)                                                                                          \
+  hipLaunchKernelGGL((k_step<I, Pol>), grid, block, h->lds_bytes, s, h->P, actions, rec, act_out, iters,       \
+                     policy_seed, h->iter, h->list_sel)
+  int prc;
+  if ((prc = prof_begin(h, h->ev_step, s))) return prc;
+  if (ind && policy) LAUNCH(true, true);
+  else if (ind) LAUNCH(true, false);
+  else if (policy) LAUNCH(false, true);
+  else LAUNCH(false, false);
+#undef LAUNCH
+  HIPCHK(hipGetLastError());
+  if ((prc = prof_end(h, h->ev_step, s))) return prc;
+  h->iter += (uint64_t)iters;
+  h->pending_deals++;
+  return SKYJO_OK;
+}
+
+int fetch_record(skyjo_vec *h, const uint4 *base, int game, std::vector<uint8_t> &raw, hipStream_t s) {
+  const SkLayout &L = h->P.L;
+  raw.assign((size_t)L.state_bytes, 0);
+  const uint8_t *src = (const uint8_t *)(base + ((size_t)(game / SK_TILE) * L.chunks) * SK_TILE + game % SK_TILE);
+  HIPCHK(hipMemcpy2DAsync(raw.data(), 16, src, SK_TILE * 16, 16, L.chunks, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return SKYJO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *skyjo_vec_last_error(void) { return g_err.c_str(); }
+int skyjo_vec_abi_version(void) { return SKYJO_ABI_VERSION; }
+
+int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
+  if (!cfg || !out) return fail(SKYJO_E_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->abi_version != SKYJO_ABI_VERSION) return fail(SKYJO_E_INVALID, "abi_version mismatch");
+  if (cfg->num_envs <= 0) return fail(SKYJO_E_INVALID, "num_envs must be > 0");
+  if (cfg->num_players <= 0 || cfg->num_players > SKYJO_MAX_PLAYERS)  // skyjo.py:24-26
+    return fail(SKYJO_E_INVALID, "Skyjo can be played from 1 up to 8 (recommended) / 12 (theoretical) players");
+  if (cfg->rng_mode != SKYJO_RNG_MT19937 && cfg->rng_mode != SKYJO_RNG_PHILOX)
+    return fail(SKYJO_E_INVALID, "unknown rng_mode");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(SKYJO_E_NOGPU, "no HIP device visible: this library has no CPU fallback");
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(SKYJO_E_INVALID, "device_id out of range");
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, cfg->device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("SKYJO_ALLOW_ANY_GPU"))
+    return fail(SKYJO_E_NOGPU, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950");
+  HIPCHK(hipSetDevice(cfg->device_id));
+
+  skyjo_vec *h = new (std::nothrow) skyjo_vec();
+  if (!h) return fail(SKYJO_E_INVALID, "out of host memory");
+  h->cfg = *cfg;
+  SkParams &P = h->P;
+  P.L = sk_make_layout(cfg->num_players, cfg->observe_indirect);
+  P.B = cfg->num_envs;
+  P.tiles = (cfg->num_envs + SK_TILE - 1) / SK_TILE;
+  P.rng_mode = cfg->rng_mode;
+  P.auto_reset = cfg->auto_reset ? 1 : 0;
+  P.score_penalty = cfg->score_penalty, P.mean_reward = cfg->mean_reward;
+  P.reward_refunded = cfg->reward_refunded, P.illegal_reward = cfg->illegal_reward;
+  P.game_id0 = cfg->game_id0;
+  h->G = (size_t)P.tiles * SK_TILE;
+  h->lds_bytes = (size_t)P.L.chunks * 1024;
+  const size_t rec16 = (size_t)P.tiles * P.L.chunks * SK_TILE;
+  int rc = SKYJO_OK;
+  const size_t N = (size_t)cfg->num_players;
+  if ((rc = dalloc(h, &P.state, rec16)) || (rc = dalloc(h, &P.spare, rec16)) ||
+      (rc = dalloc(h, &P.spare_ready, h->G)) || (rc = dalloc(h, &P.rng_sel, h->G)) ||
+      (rc = dalloc(h, &P.mt_idx, 2 * h->G)) || (rc = dalloc(h, &P.seeds, h->G)) ||
+      (rc = dalloc(h, &P.deals_consumed, h->G)) || (rc = dalloc(h, &P.rewards, h->G * N)) ||
+      (rc = dalloc(h, &P.scores, h->G * N)) || (rc = dalloc(h, &P.done, h->G)) ||
+      (rc = dalloc(h, &P.refill_list, 2 * h->G)) || (rc = dalloc(h, &P.refill_count, 2)) ||
+      (rc = dalloc(h, &P.counters, 1))) {
+    skyjo_vec_destroy(h);
+    return rc;
+  }
+  if (cfg->rng_mode == SKYJO_RNG_MT19937 && (rc = dalloc(h, &P.mt, 2 * h->G * 624, false))) {
+    skyjo_vec_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return SKYJO_OK;
+}
+
+int skyjo_vec_destroy(skyjo_vec *h) {
+  if (!h) return SKYJO_OK;
+  (void)hipDeviceSynchronize();
+  for (void *p : h->allocs) (void)hipFree(p);
+  delete h;
+  return SKYJO_OK;
+}
+
+int skyjo_vec_get_info(const skyjo_vec *h, skyjo_vec_info *out) {
+  if (!h || !out) return fail(SKYJO_E_INVALID, "null argument");
+  const SkLayout &L = h->P.L;
+  out->num_envs = h->P.B, out->num_players = L.N, out->obs_dim = L.D, out->record_bytes = L.rec_bytes;
+  out->mask_offset = L.Dp, out->meta_offset = L.Dp + 26, out->state_bytes = L.state_bytes, out->tile_games = SK_TILE;
+  return SKYJO_OK;
+}
+
+int skyjo_vec_seed(skyjo_vec *h, const uint64_t *seeds_host, uint64_t base_seed, void *stream) {
+  if (!h) return fail(SKYJO_E_INVALID, "null handle");
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(h->cfg.device_id));
+  uint64_t *d_seeds = nullptr;
+  if (seeds_host) {
+    HIPCHK(hipMalloc((void **)&d_seeds, sizeof(uint64_t) * (size_t)h->P.B));
+    HIPCHK(hipMemcpyAsync(d_seeds, seeds_host, sizeof(uint64_t) * (size_t)h->P.B, hipMemcpyHostToDevice, s));
+  }
+  HIPCHK(hipMemsetAsync(h->P.refill_count, 0, 2 * sizeof(uint32_t), s));
+  HIPCHK(hipMemsetAsync(h->P.done, 0, h->G, s));
+  hipLaunchKernelGGL(k_seed, dim3((h->P.B + 255) / 256), dim3(256), 0, s, h->P, (const uint64_t *)d_seeds, base_seed, 0,
+                     h->P.B);
+  HIPCHK(hipGetLastError());
+  int rc;
+  // set_seed deals immediately (skyjo.py:88): deal #0 becomes the live game, deal #1 is pre-dealt
+  if ((rc = launch_deal(h, s, true))) return rc;
+  h->seeded = true;
+  if ((rc = skyjo_vec_reset(h, nullptr, nullptr, stream))) return rc;
+  if (d_seeds) {
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipFree(d_seeds));
+  }
+  h->iter = 0;
+  return skyjo_vec_reset_counters(h, stream);
+}
+
+int skyjo_vec_reset(skyjo_vec *h, const uint8_t *mask, void *records_out, void *stream) {
+  if (!h) return fail(SKYJO_E_INVALID, "null handle");
+  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (h->pending_deals > 0 && (rc = launch_deal(h, s, false))) return rc;  // make every next deal available
+  dim3 grid(h->P.tiles), block(SK_TILE);
+  if (h->P.L.indirect)
+    hipLaunchKernelGGL((k_reset<true>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out, h->list_sel);
+  else
+    hipLaunchKernelGGL((k_reset<false>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out, h->list_sel);
+  HIPCHK(hipGetLastError());
+  return launch_deal(h, s, false);
+}
+
+int skyjo_vec_step(skyjo_vec *h, const int32_t *actions, void *records_out, void *stream) {
+  if (!h || !actions) return fail(SKYJO_E_INVALID, "null argument");
+  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = launch_step(h, s, false, actions, (uint8_t *)records_out, nullptr, 1, 0);
+  if (rc) return rc;
+  if (h->pending_deals >= h->deal_interval) return launch_deal(h, s, false);
+  return SKYJO_OK;
+}
+
+int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *records_out, int32_t *actions_out,
+                      void *stream) {
+  if (!h || iters < 0) return fail(SKYJO_E_INVALID, "bad argument");
+  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  hipStream_t s = (hipStream_t)stream;
+  uint8_t *rec = (uint8_t *)records_out;
+  for (int done = 0; done < iters;) {
+    const int n = iters - done < kMaxRolloutChunk ? iters - done : kMaxRolloutChunk;
+    int rc = launch_step(h, s, true, nullptr, rec, actions_out, n, policy_seed);
+    if (rc) return rc;
+    if ((rc = launch_deal(h, s, false))) return rc;
+    if (rec) rec += (size_t)n * h->P.B * h->P.L.rec_bytes;
+    if (actions_out) actions_out += (size_t)n * h->P.B;
+    done += n;
+  }
+  return SKYJO_OK;
+}
+
+int skyjo_vec_observe(skyjo_vec *h, const int32_t *players, void *records_out, void *stream) {
+  if (!h || !records_out) return fail(SKYJO_E_INVALID, "null argument");
+  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  dim3 grid(h->P.tiles), block(SK_TILE);
+  hipStream_t s = (hipStream_t)stream;
+  if (h->P.L.indirect)
+    hipLaunchKernelGGL((k_observe<true>), grid, block, h->lds_bytes, s, h->P, players, (uint8_t *)records_out);
+  else
+    hipLaunchKernelGGL((k_observe<false>), grid, block, h->lds_bytes, s, h->P, players, (uint8_t *)records_out);
+  HIPCHK(hipGetLastError());
+  return SKYJO_OK;
+}
+
+int skyjo_vec_unpack(skyjo_vec *h, const void *records, int64_t n, int8_t *obs, int8_t *mask, uint8_t *agent,
+                     uint8_t *phase, uint8_t *done, uint8_t *status, void *stream) {
+  if (!h || !records || n < 0) return fail(SKYJO_E_INVALID, "bad argument");
+  if (n == 0) return SKYJO_OK;
+  long long total = n * (long long)(h->P.L.D + 26);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h->P.L, (const uint8_t *)records,
+                     (long long)n, obs, mask, agent, phase, done, status);
+  HIPCHK(hipGetLastError());
+  return SKYJO_OK;
+}
+
+const double *skyjo_vec_rewards_ptr(const skyjo_vec *h) { return h ? h->P.rewards : nullptr; }
+const double *skyjo_vec_scores_ptr(const skyjo_vec *h) { return h ? h->P.scores : nullptr; }
+const uint8_t *skyjo_vec_done_ptr(const skyjo_vec *h) { return h ? h->P.done : nullptr; }
+
+int skyjo_vec_get_counters(skyjo_vec *h, skyjo_vec_counters *out, void *stream) {
+  if (!h || !out) return fail(SKYJO_E_INVALID, "null argument");
+  static_assert(sizeof(SkCounters) == sizeof(skyjo_vec_counters), "counter structs must match");
+  HIPCHK(hipMemcpyAsync(out, h->P.counters, sizeof(SkCounters), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return SKYJO_OK;
+}
+
+int skyjo_vec_reset_counters(skyjo_vec *h, void *stream) {
+  if (!h) return fail(SKYJO_E_INVALID, "null handle");
+  HIPCHK(hipMemsetAsync(h->P.counters, 0, sizeof(SkCounters), (hipStream_t)stream));
+  return SKYJO_OK;
+}
+
+int skyjo_vec_get_state(skyjo_vec *h, int32_t game, skyjo_game_state *o, void *stream) {
+  if (!h || !o || game < 0 || game >= h->P.B) return fail(SKYJO_E_INVALID, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const SkLayout &L = h->P.L;
+  std::vector<uint8_t> r;
+  int rc = fetch_record(h, h->P.state, game, r, s);
+  if (rc) return rc;
+  memset(o, 0, sizeof(*o));
+  for (int p = 0; p < L.N; p++)
+    for (int k = 0; k < 12; k++) {
+      int8_t c = (int8_t)r[L.off_cards + 12 * p + k], v = (int8_t)r[L.off_vis + 12 * p + k];
+      o->players_cards[p][k] = c;
+      o->players_masked[p][k] = v == SKYJO_HAND_NONE ? 2 : (v == SKYJO_REFUNDED ? 0 : 1);
+    }
+  const int role = r[H_ROLE];
+  o->n_draw = r[H_NDRAW], o->n_disc = r[H_NDISC];
+  for (int k = 0; k < o->n_draw; k++) o->drawpile[k] = (int8_t)r[L.off_pile + (role ? SK_NCARDS - 1 - k : k)];
+  for (int k = 0; k < o->n_disc; k++) o->discard_pile[k] = (int8_t)r[L.off_pile + (role ? k : SK_NCARDS - 1 - k)];
+  o->hand_card = (int8_t)r[H_HAND];
+  o->expected_player = r[H_PLAYER], o->expected_phase = r[H_PHASE];
+  o->is_terminated = (r[H_FLAGS] & F_TERMINATED) ? 1 : 0;
+  o->done = (r[H_FLAGS] & F_DONE) ? 1 : 0;
+  o->status = r[H_STATUS];
+  memcpy(&o->episode_steps, &r[H_EPLEN], 2);
+  memcpy(&o->episode, &r[H_EPISODE], 4);
+  o->reshuffles = r[H_RESH];
+  for (int p = 0; p < L.N; p++) {
+    o->num_refunded[p] = r[L.off_refunded + p];
+    uint16_t pl;
+    memcpy(&pl, &r[L.off_placed + 2 * p], 2);
+    o->num_placed[p] = pl;
+  }
+  if (o->done) {
+    HIPCHK(hipMemcpyAsync(o->rewards, h->P.rewards + (size_t)game * L.N, sizeof(double) * L.N, hipMemcpyDeviceToHost, s));
+    if (o->is_terminated)
+      HIPCHK(hipMemcpyAsync(o->final_score, h->P.scores + (size_t)game * L.N, sizeof(double) * L.N,
+                            hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  return SKYJO_OK;
+}
+
+int skyjo_vec_set_state(skyjo_vec *h, int32_t game, const skyjo_game_state *in, void *stream) {
+  if (!h || !in || game < 0 || game >= h->P.B) return fail(SKYJO_E_INVALID, "bad argument");
+  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  const SkLayout &L = h->P.L;
+  if (in->n_draw < 0 || in->n_disc < 0 || in->n_draw + in->n_disc > SK_NCARDS)
+    return fail(SKYJO_E_INVALID, "pile sizes out of range");
+  if (in->expected_player >= L.N || in->expected_phase > 1) return fail(SKYJO_E_INVALID, "bad expected action");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<uint8_t> r((size_t)L.state_bytes, 0);
+  int ms = 1 << 30, mh = 1 << 30;
+  for (int p = 0; p < L.N; p++) {
+    int sum = 0, hid = 0;
+    for (int k = 0; k < 12; k++) {
+      int8_t c = in->players_cards[p][k];
+      int m = in->players_masked[p][k];
+      if (c < -2 && !(m == 0 && c == SKYJO_REFUNDED)) return fail(SKYJO_E_INVALID, "card value out of range");
+      if (c > 12) return fail(SKYJO_E_INVALID, "card value out of range");
+      int8_t v = m == 2 ? (int8_t)SKYJO_HAND_NONE : (m == 0 ? (int8_t)SKYJO_REFUNDED : c);
+      r[L.off_cards + 12 * p + k] = (uint8_t)(m == 0 ? (int8_t)SKYJO_REFUNDED : c);
+      r[L.off_vis + 12 * p + k] = (uint8_t)v;
+      if (m == 1) {
+        sum += c;
+        if (!L.indirect) r[H_HIST + 2 + c]++;
+      }
+      if (m == 2) hid++;
+    }
+    int16_t s16 = (int16_t)sum;
+    memcpy(&r[L.off_sums + 2 * p], &s16, 2);
+    r[L.off_hidden + p] = (uint8_t)hid;
+    r[L.off_refunded + p] = (uint8_t)in->num_refunded[p];
+    uint16_t pl = (uint16_t)in->num_placed[p];
+    memcpy(&r[L.off_placed + 2 * p], &pl, 2);
+    ms = sum < ms ? sum : ms, mh = hid < mh ? hid : mh;
+  }
+  for (int k = 0; k < in->n_draw; k++) r[L.off_pile + k] = (uint8_t)in->drawpile[k];
+  for (int k = 0; k < in->n_disc; k++) {
+    int8_t c = in->discard_pile[k];
+    if (c < -2 || c > 12) return fail(SKYJO_E_INVALID, "discard value out of range");
+    r[L.off_pile + SK_NCARDS - 1 - k] = (uint8_t)c;
+    r[H_HIST + 2 + c]++;
+  }
+  r[H_PHASE] = in->expected_phase, r[H_PLAYER] = in->expected_player;
+  r[H_FLAGS] = F_VALID | (in->is_terminated ? (F_TERMINATED | F_DONE) : 0) | (in->done ? F_DONE : 0);
+  r[H_STATUS] = in->status;
+  r[H_NDRAW] = (uint8_t)in->n_draw, r[H_NDISC] = (uint8_t)in->n_disc, r[H_ROLE] = 0;
+  memcpy(&r[H_EPLEN], &in->episode_steps, 2);
+  r[H_RESH] = (uint8_t)(in->reshuffles > 255 ? 255 : in->reshuffles);
+  memcpy(&r[H_EPISODE], &in->episode, 4);
+  r[H_MINSUM] = (uint8_t)(int8_t)(ms < 127 ? ms : 127);
+  r[H_MINHID] = (uint8_t)mh;
+  r[H_TOP] = in->n_disc ? (uint8_t)in->discard_pile[in->n_disc - 1] : (uint8_t)(int8_t)-3;
+  r[H_HAND] = (uint8_t)in->hand_card;
+  uint8_t *dst = (uint8_t *)(h->P.state + ((size_t)(game / SK_TILE) * L.chunks) * SK_TILE + game % SK_TILE);
+  HIPCHK(hipMemcpy2DAsync(dst, SK_TILE * 16, r.data(), 16, 16, L.chunks, hipMemcpyHostToDevice, s));
+  uint8_t dn = (r[H_FLAGS] & F_DONE) ? 1 : 0;
+  HIPCHK(hipMemcpyAsync(h->P.done + game, &dn, 1, hipMemcpyHostToDevice, s));
+  if (dn) {
+    HIPCHK(hipMemcpyAsync(h->P.rewards + (size_t)game * L.N, in->rewards, sizeof(double) * L.N, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->P.scores + (size_t)game * L.N, in->final_score, sizeof(double) * L.N,
+                          hipMemcpyHostToDevice, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return SKYJO_OK;
+}
+
+__global__ void k_invalidate_spare(SkParams P, int g, int list_sel) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && P.spare_ready[g]) {
+    P.spare_ready[g] = 0;
+    refill_request(P, g, list_sel);
+  }
+}
+
+int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream) {
+  if (!h || game < 0 || game >= h->P.B) return fail(SKYJO_E_INVALID, "bad argument");
+  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  if (h->P.rng_mode != SKYJO_RNG_MT19937) return fail(SKYJO_E_STATE, "seed_raw needs the MT19937 mode");
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (h->pending_deals > 0 && (rc = launch_deal(h, s, false))) return rc;
+  hipLaunchKernelGGL(k_seed_raw, dim3(1), dim3(64), 0, s, h->P, game, value);
+  hipLaunchKernelGGL(k_invalidate_spare, dim3(1), dim3(64), 0, s, h->P, game, h->list_sel);
+  HIPCHK(hipGetLastError());
+  return launch_deal(h, s, false);
+}
+
+int skyjo_vec_profile(skyjo_vec *h, int enable, double *step_ms, int64_t *step_launches, double *deal_ms,
+                      int64_t *deal_launches) {
+  if (!h) return fail(SKYJO_E_INVALID, "null handle");
+  HIPCHK(hipDeviceSynchronize());
+  double tot[2] = {0, 0};
+  int64_t cnt[2] = {0, 0};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> *v[2] = {&h->ev_step, &h->ev_deal};
+  for (int k = 0; k < 2; k++) {
+    for (auto &p : *v[k]) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) tot[k] += ms, cnt[k]++;
+      (void)hipEventDestroy(p.first);
+      (void)hipEventDestroy(p.second);
+    }
+    v[k]->clear();
+  }
+  if (step_ms) *step_ms = tot[0];
+  if (step_launches) *step_launches = cnt[0];
+  if (deal_ms) *deal_ms = tot[1];
+  if (deal_launches) *deal_launches = cnt[1];
+  h->profile = enable != 0;
+  return SKYJO_OK;
+}
+
+int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
+  if (!h) return fail(SKYJO_E_INVALID, "null handle");
+  switch (option) {
+    case SKYJO_OPT_DEAL_INTERVAL:
+      if (value < 1 || value > 64) return fail(SKYJO_E_INVALID, "deal interval must be in 1..64");
+      h->deal_interval = (int)value;
+      return SKYJO_OK;
+    default:
+      return fail(SKYJO_E_INVALID, "unknown option");
+  }
+}
+
+// ---- host-pointer conveniences ------------------------------------------------------------
+static int ensure_scratch(skyjo_vec *h) {
+  int rc;
+  if (!h->d_actions && (rc = dalloc(h, &h->d_actions, h->G))) return rc;
+  if (!h->d_records && (rc = dalloc(h, &h->d_records, h->G * (size_t)h->P.L.rec_bytes))) return rc;
+  if (!h->d_mask && (rc = dalloc(h, &h->d_mask, h->G))) return rc;
+  return SKYJO_OK;
+}
+
+int skyjo_vec_step_host(skyjo_vec *h, const int32_t *actions_host, void *records_out_host) {
+  if (!h || !actions_host) return fail(SKYJO_E_INVALID, "null argument");
+  int rc = ensure_scratch(h);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(h->d_actions, actions_host, sizeof(int32_t) * (size_t)h->P.B, hipMemcpyHostToDevice));
+  if ((rc = skyjo_vec_step(h, h->d_actions, h->d_records, nullptr))) return rc;
+  if (records_out_host)
+    HIPCHK(hipMemcpy(records_out_host, h->d_records, (size_t)h->P.B * h->P.L.rec_bytes, hipMemcpyDeviceToHost));
+  else
+    HIPCHK(hipStreamSynchronize(nullptr));
+  return SKYJO_OK;
+}
+
+int skyjo_vec_observe_host(skyjo_vec *h, const int32_t *players_host, void *records_out_host) {
+  if (!h || !records_out_host) return fail(SKYJO_E_INVALID, "null argument");
+  int rc = ensure_scratch(h);
+  if (rc) return rc;
+  if (players_host)
+    HIPCHK(hipMemcpy(h->d_actions, players_host, sizeof(int32_t) * (size_t)h->P.B, hipMemcpyHostToDevice));
+  if ((rc = skyjo_vec_observe(h, players_host ? h->d_actions : nullptr, h->d_records, nullptr))) return rc;
+  HIPCHK(hipMemcpy(records_out_host, h->d_records, (size_t)h->P.B * h->P.L.rec_bytes, hipMemcpyDeviceToHost));
+  return SKYJO_OK;
+}
+
+int skyjo_vec_reset_host(skyjo_vec *h, const uint8_t *mask_host, void *records_out_host) {
+  if (!h) return fail(SKYJO_E_INVALID, "null handle");
+  int rc = ensure_scratch(h);
+  if (rc) return rc;
+  if (mask_host) HIPCHK(hipMemcpy(h->d_mask, mask_host, (size_t)h->P.B, hipMemcpyHostToDevice));
+  if ((rc = skyjo_vec_reset(h, mask_host ? h->d_mask : nullptr, h->d_records, nullptr))) return rc;
+  if (records_out_host)
+    HIPCHK(hipMemcpy(records_out_host, h->d_records, (size_t)h->P.B * h->P.L.rec_bytes, hipMemcpyDeviceToHost));
+  else
+    HIPCHK(hipStreamSynchronize(nullptr));
+  return SKYJO_OK;
+}
+
+int skyjo_vec_get_rewards_host(skyjo_vec *h, double *rewards_out, double *scores_out, uint8_t *done_out) {
+  if (!h) return fail(SKYJO_E_INVALID, "null handle");
+  const size_t n = (size_t)h->P.B * h->P.L.N;
+  if (rewards_out) HIPCHK(hipMemcpy(rewards_out, h->P.rewards, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (scores_out) HIPCHK(hipMemcpy(scores_out, h->P.scores, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (done_out) HIPCHK(hipMemcpy(done_out, h->P.done, (size_t)h->P.B, hipMemcpyDeviceToHost));
+  return SKYJO_OK;
+}
+
+int skyjo_dev_malloc(int device_id, size_t bytes, void **out) {
+  if (!out) return fail(SKYJO_E_INVALID, "null argument");
+  HIPCHK(hipSetDevice(device_id));
+  HIPCHK(hipMalloc(out, bytes ? bytes : 1));
+  return SKYJO_OK;
+}
+int skyjo_dev_free(void *p) {
+  if (p) HIPCHK(hipFree(p));
+  return SKYJO_OK;
+}
+int skyjo_dev_copy(void *dst, const void *src, size_t bytes, int kind, void *stream) {
+  hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, k, (hipStream_t)stream));
+  if (kind == 2) HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return SKYJO_OK;
+}
+int skyjo_dev_sync(void *stream) {
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return SKYJO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,749 @@
+// skyjo_device.h - gfx950 device code of the vectorised SkyJo environment.
+//
+// Execution model: one wavefront (64 lanes) owns one TILE of 64 games; lane l owns game l of
+// the tile for the whole launch.  The tile's packed state is streamed HBM -> LDS with coalesced
+// 16-byte-per-lane loads, every data-dependent byte access of the transition (card slots, pile
+// tops, histogram bins) then hits the lane's private LDS bank (skyjo_layout.h), and the tile is
+// streamed back once per launch.  No MFMA: the path is integer / control work bounded by HBM
+// traffic (DESIGN.md has the byte counts).
+//
+// Semantics follow rlskyjo/game/skyjo.py and rlskyjo/environment/skyjo_env.py; each function
+// cites the lines it restates.  Nothing here shares code with oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/skyjo_vec.h"
+#include "skyjo_layout.h"
+
+struct SkCounters {
+  unsigned long long steps, episodes, illegal, resets, sum_len, reshuffles, iters, waits;
+  double sum_score[SKYJO_MAX_PLAYERS];
+  double sum_reward[SKYJO_MAX_PLAYERS];
+};
+
+struct SkParams {
+  SkLayout L;
+  int32_t B, tiles, rng_mode, auto_reset;
+  double score_penalty, mean_reward, reward_refunded, illegal_reward;
+  uint64_t game_id0;
+  uint4 *state;             // [tiles][chunks][64] live games
+  uint4 *spare;             // [tiles][chunks][64] pre-dealt next episode of every game
+  uint8_t *spare_ready;     // [tiles*64]
+  uint8_t *rng_sel;         // [tiles*64] which MT19937 buffer is current
+  uint32_t *mt;             // [2][tiles*64][624] numpy-legacy MT19937 state (MT mode only)
+  int32_t *mt_idx;          // [2][tiles*64]
+  uint64_t *seeds;          // [tiles*64] value given to set_seed
+  uint32_t *deals_consumed; // [tiles*64]
+  double *rewards;          // [tiles*64][N]
+  double *scores;           // [tiles*64][N]
+  uint8_t *done;            // [tiles*64]
+  int32_t *refill_list;     // [2][tiles*64]
+  uint32_t *refill_count;   // [2]
+  SkCounters *counters;
+};
+
+struct LaneCounters {
+  uint32_t steps = 0, episodes = 0, illegal = 0, resets = 0, sum_len = 0, reshuffles = 0, waits = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// LDS addressing: lp = tile base + lane * 4 ; byte b of this lane's record lives at lp[LIDX(b)]
+// ------------------------------------------------------------------------------------------
+#define LIDX(b) ((((b) >> 2) << 8) | ((b) & 3))
+#define LB(b) (lp[LIDX(b)])
+#define LI(b) ((int)(int8_t)lp[LIDX(b)])
+#define LW(w) (*(uint32_t *)(lp + ((w) << 8)))
+#define LH(b) (*(uint16_t *)(lp + LIDX(b)))
+#define LSH(b) (*(int16_t *)(lp + LIDX(b)))
+
+__device__ __forceinline__ void tile_load(const SkParams &P, const uint4 *src, int tile, int lane, uint8_t *lp) {
+  const uint4 *s = src + (size_t)tile * P.L.chunks * SK_TILE + lane;
+  for (int c = 0; c < P.L.chunks; c++) {
+    uint4 v = s[(size_t)c * SK_TILE];
+    LW(4 * c + 0) = v.x, LW(4 * c + 1) = v.y, LW(4 * c + 2) = v.z, LW(4 * c + 3) = v.w;
+  }
+}
+
+__device__ __forceinline__ void tile_store(const SkParams &P, uint4 *dst, int tile, int lane, uint8_t *lp) {
+  uint4 *d = dst + (size_t)tile * P.L.chunks * SK_TILE + lane;
+  for (int c = 0; c < P.L.chunks; c++) {
+    uint4 v;
+    v.x = LW(4 * c + 0), v.y = LW(4 * c + 1), v.z = LW(4 * c + 2), v.w = LW(4 * c + 3);
+    d[(size_t)c * SK_TILE] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// RNG.  MT mode restates numpy's legacy RandomState (requirements.txt:3 pins numpy==1.21.5; call
+// sites skyjo.py:81,94,101,135): init_genrand, tempering, rk_interval, Fisher-Yates.  The state
+// lives in HBM (2496 B per game, touched only when dealing / reshuffling) and is regenerated
+// lazily: element i of the next block is produced right before it is consumed, which yields the
+// same stream as the classic 624-word block twist.
+// ------------------------------------------------------------------------------------------
+struct MtStream {
+  uint32_t *mt;
+  int idx;
+  __device__ __forceinline__ uint32_t next() {
+    if (idx >= 624) idx = 0;
+    const int i = idx;
+    uint32_t a = mt[i], b = mt[i == 623 ? 0 : i + 1], c = mt[i < 227 ? i + 397 : i - 227];
+    uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    uint32_t v = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    mt[i] = v;
+    idx = i + 1;
+    v ^= v >> 11;
+    v ^= (v << 7) & 0x9d2c5680u;
+    v ^= (v << 15) & 0xefc60000u;
+    v ^= v >> 18;
+    return v;
+  }
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0, c1 = l1, c2 = n2, c3 = l0;
+    k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+  }
+  o0 = c0, o1 = c1, o2 = c2, o3 = c3;
+}
+
+// Philox "session": ctr = (block, episode, reshuffle index, domain), key = seed + 1.
+struct PhiloxStream {
+  uint32_t k0, k1, blk, c1, c2, c3, b0, b1, b2, b3;
+  int pos;
+  __device__ __forceinline__ void open(uint64_t key, uint32_t episode, uint32_t resh, uint32_t domain) {
+    k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32), blk = 0, c1 = episode, c2 = resh, c3 = domain, pos = 4;
+  }
+  __device__ __forceinline__ uint32_t next() {
+    if (pos >= 4) {
+      philox4x32_10(blk, c1, c2, c3, k0, k1, b0, b1, b2, b3);
+      blk++, pos = 0;
+    }
+    uint32_t v = pos == 0 ? b0 : pos == 1 ? b1 : pos == 2 ? b2 : b3;
+    pos++;
+    return v;
+  }
+};
+
+// legacy rk_interval (32-bit path): smallest all-ones mask >= max, rejection sampling
+template <class Rng>
+__device__ __forceinline__ uint32_t rng_interval(Rng &r, uint32_t max) {
+  uint32_t mask = 0xffffffffu >> __clz((int)(max | 1u));
+  uint32_t v;
+  do v = r.next() & mask;
+  while (v > max);
+  return v;
+}
+
+// pile addressing: region A grows up from byte 0, region B grows down from byte 149.
+// role 0: draw pile in A, discard pile in B; a mid-game reshuffle flips the role.
+__device__ __forceinline__ int pile_addr(int region_b, int k) { return region_b ? (SK_NCARDS - 1 - k) : k; }
+
+// ------------------------------------------------------------------------------------------
+// min over players of revealed sums / hidden counts -> obs[0], obs[1] (skyjo.py:182-183)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void refresh_minima(const SkParams &P, uint8_t *lp) {
+  int ms = LSH(P.L.off_sums), mh = LB(P.L.off_hidden);
+  for (int q = 1; q < P.L.N; q++) {
+    int s = LSH(P.L.off_sums + 2 * q), h = LB(P.L.off_hidden + q);
+    ms = s < ms ? s : ms, mh = h < mh ? h : mh;
+  }
+  LB(H_MINSUM) = (uint8_t)(int8_t)(ms < 127 ? ms : 127);
+  LB(H_MINHID) = (uint8_t)mh;
+}
+
+// ------------------------------------------------------------------------------------------
+// _reshuffle_discard_pile mid-game (skyjo.py:127-138, 361-365): the WHOLE discard pile incl. its
+// top is shuffled in place, becomes the draw pile, and its last card opens the new discard pile.
+// ------------------------------------------------------------------------------------------
+template <class Rng>
+__device__ __forceinline__ void reshuffle_discard(const SkParams &P, uint8_t *lp, Rng &r) {
+  const int n = LB(H_NDISC), role = LB(H_ROLE), pb = P.L.off_pile;
+  const int reg = role ? 0 : 1;  // region holding the discard pile
+  for (int i = n - 1; i >= 1; i--) {
+    int j = (int)rng_interval(r, (uint32_t)i);
+    int ai = pb + pile_addr(reg, i), aj = pb + pile_addr(reg, j);
+    uint8_t t = LB(ai);
+    LB(ai) = LB(aj), LB(aj) = t;
+  }
+  // cards that leave the discard pile leave the histogram (skyjo.py:236-248 counts the pile)
+  for (int k = 0; k < n - 1; k++) LB(H_HIST + 2 + LI(pb + pile_addr(reg, k)))--;
+  int last = LI(pb + pile_addr(reg, n - 1));
+  LB(pb + pile_addr(reg ^ 1, 0)) = (uint8_t)last;
+  LB(H_NDRAW) = (uint8_t)(n - 1), LB(H_NDISC) = 1, LB(H_ROLE) = (uint8_t)(role ^ 1);
+  LB(H_TOP) = (uint8_t)last;
+  int rs = LB(H_RESH);
+  LB(H_RESH) = (uint8_t)(rs < 255 ? rs + 1 : 255);
+}
+
+__device__ __forceinline__ void refill_request(const SkParams &P, int g, int list_sel) {
+  uint32_t slot = atomicAdd(&P.refill_count[list_sel], 1u);
+  P.refill_list[(size_t)list_sel * P.tiles * SK_TILE + slot] = g;
+}
+
+__device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *lp, int g, int list_sel) {
+  if (P.rng_mode == SKYJO_RNG_MT19937) {
+    const size_t G = (size_t)P.tiles * SK_TILE;
+    const int sel = P.rng_sel[g];
+    MtStream r{P.mt + ((size_t)sel * G + g) * 624, P.mt_idx[(size_t)sel * G + g]};
+    reshuffle_discard(P, lp, r);
+    P.mt_idx[(size_t)sel * G + g] = r.idx;
+    // the pre-dealt next episode was drawn from the stream position before this reshuffle: re-deal it
+    if (P.spare_ready[g]) {
+      P.spare_ready[g] = 0;
+      refill_request(P, g, list_sel);
+    }
+  } else {
+    PhiloxStream r;
+    r.open(P.seeds[g] + 1, *(uint32_t *)(lp + LIDX(H_EPISODE)), LB(H_RESH), 1u);
+    reshuffle_discard(P, lp, r);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// _evaluate_game + _calc_final_rewards (skyjo.py:477-498, skyjo_env.py:293-312), float64, no FMA
+// contraction (compiled with -ffp-contract=off), numpy's pairwise summation order for the mean.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void finish_game(const SkParams &P, uint8_t *lp, int g, int finisher) {
+  const int N = P.L.N;
+  double *sc = P.scores + (size_t)g * N, *rw = P.rewards + (size_t)g * N;
+  double mn = 0.0;
+  for (int p = 0; p < N; p++) {
+    int s = 0;
+    for (int c = 0; c < 4; c++) {
+      int b = P.L.off_cards + 12 * p + 3 * c;
+      int t0 = LI(b), t1 = LI(b + 1), t2 = LI(b + 2);
+      if (!(t0 == t1 && t1 == t2)) s += t0 + t1 + t2;
+    }
+    double d = (double)s;
+    sc[p] = d;
+    mn = (p == 0 || d < mn) ? d : mn;
+  }
+  double fs = sc[finisher];
+  if (mn != fs) sc[finisher] = fs * P.score_penalty;  // skyjo.py:496-497
+  double sum;
+  if (N < 8) {
+    sum = 0.0;
+    for (int p = 0; p < N; p++) sum += sc[p];
+  } else {
+    double r0 = sc[0], r1 = sc[1], r2 = sc[2], r3 = sc[3], r4 = sc[4], r5 = sc[5], r6 = sc[6], r7 = sc[7];
+    sum = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (int p = 8; p < N; p++) sum += sc[p];
+  }
+  double mean = sum / (double)N;
+  for (int p = 0; p < N; p++) {
+    double r = (-sc[p] + mean) + P.mean_reward;
+    if (P.reward_refunded != 0.0) r += (double)LB(P.L.off_refunded + p) * P.reward_refunded;
+    rw[p] = r;
+    atomicAdd(&P.counters->sum_score[p], sc[p]);
+    atomicAdd(&P.counters->sum_reward[p], r);
+  }
+  P.done[g] = 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// SkyjoGame.act (skyjo.py:308-335) for the expected player, preceded by the legality test of
+// TerminateIllegalWrapper (skyjo_env.py:23) on the action mask of skyjo.py:201-224.
+// Caller guarantees the game is valid and not done.
+// ------------------------------------------------------------------------------------------
+template <bool INDIRECT>
+__device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, int a, int g, int list_sel,
+                                             LaneCounters &cnt) {
+  const int N = P.L.N;
+  const int phase = LB(H_PHASE), p = LB(H_PLAYER);
+  const int visb = P.L.off_vis + 12 * p, cardb = P.L.off_cards + 12 * p, pb = P.L.off_pile;
+  const unsigned ua = (unsigned)a;
+  int slot = 0, sv = 0;
+  bool legal;
+  if (ua < 24u) {
+    slot = a < 12 ? a : a - 12;
+    sv = LI(visb + slot);
+    legal = phase == 1 && (a < 12 ? sv != SKYJO_REFUNDED : sv == SKYJO_HAND_NONE);
+  } else {
+    legal = ua <= 25u && phase == 0;
+  }
+  if (!legal) {  // offender gets illegal_reward, everybody else 0, all done
+    double *rw = P.rewards + (size_t)g * N;
+    for (int q = 0; q < N; q++) rw[q] = q == p ? P.illegal_reward : 0.0;
+    atomicAdd(&P.counters->sum_reward[p], P.illegal_reward);
+    LB(H_FLAGS) |= F_DONE;
+    LB(H_STATUS) = SKYJO_ST_ILLEGAL;
+    P.done[g] = 1;
+    cnt.illegal++;
+    return;
+  }
+  LB(H_STATUS) = SKYJO_ST_OK;
+  const int eplen = LH(H_EPLEN) + 1;
+  LH(H_EPLEN) = (uint16_t)eplen;
+  cnt.steps++;
+  if (phase == 0) {
+    // _action_draw_card (skyjo.py:337-374): goal check first, on the drawing player
+    if (LB(P.L.off_hidden + p) == 0) {
+      LB(H_FLAGS) |= F_TERMINATED | F_DONE;
+      LB(H_FINISHER) = (uint8_t)p;
+      finish_game(P, lp, g, p);
+      cnt.episodes++;
+      cnt.sum_len += eplen;
+      return;  // nothing drawn, turn not advanced (skyjo.py:350-356)
+    }
+    int hand;
+    if (a == 24) {
+      int nd = LB(H_NDRAW);
+      if (nd == 0) {
+        reshuffle_dispatch(P, lp, g, list_sel);
+        cnt.reshuffles++;
+        nd = LB(H_NDRAW);
+      }
+      nd--;
+      hand = LI(pb + pile_addr(LB(H_ROLE), nd));
+      LB(H_NDRAW) = (uint8_t)nd;
+    } else {
+      const int reg = LB(H_ROLE) ^ 1;
+      int ns = LB(H_NDISC) - 1;
+      hand = LI(pb + pile_addr(reg, ns));
+      LB(H_HIST + 2 + hand)--;
+      LB(H_NDISC) = (uint8_t)ns;
+      LB(H_TOP) = ns > 0 ? LB(pb + pile_addr(reg, ns - 1)) : (uint8_t)(int8_t)-3;  // skyjo.py:254
+    }
+    LB(H_HAND) = (uint8_t)hand;
+    LB(H_PHASE) = 1;
+    return;
+  }
+  // _action_place (skyjo.py:376-427)
+  const int hand = LI(H_HAND);
+  const int reg = LB(H_ROLE) ^ 1;
+  int ns = LB(H_NDISC);
+  int sum = LSH(P.L.off_sums + 2 * p);
+  int top;
+  if (a < 12) {  // swap hand card with slot a; the old card (open or hidden) goes to the discard pile
+    const int old = LI(cardb + a);
+    LB(pb + pile_addr(reg, ns)) = (uint8_t)old;
+    ns++;
+    LB(H_HIST + 2 + old)++;
+    LB(cardb + a) = (uint8_t)hand;
+    LB(visb + a) = (uint8_t)hand;
+    if (sv == SKYJO_HAND_NONE) {
+      sum += hand;
+      LB(P.L.off_hidden + p)--;
+    } else {
+      sum += hand - old;
+      if (!INDIRECT) LB(H_HIST + 2 + old)--;  // an open card leaves the table (skyjo.py:240-244)
+    }
+    if (!INDIRECT) LB(H_HIST + 2 + hand)++;
+    top = old;
+  } else {  // discard the hand card and reveal slot
+    const int c = LI(cardb + slot);
+    LB(pb + pile_addr(reg, ns)) = (uint8_t)hand;
+    ns++;
+    LB(H_HIST + 2 + hand)++;
+    LB(visb + slot) = (uint8_t)c;
+    LB(P.L.off_hidden + p)--;
+    sum += c;
+    if (!INDIRECT) LB(H_HIST + 2 + c)++;
+    top = hand;
+  }
+  // _remask_refunded_player_cards_jit (skyjo.py:431-469): all 4 columns of the acting player
+  {
+    const int vw = visb >> 2;
+    uint32_t w0 = LW(vw), w1 = LW(vw + 1), w2 = LW(vw + 2);
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      uint32_t tri;  // the three bytes 3c, 3c+1, 3c+2
+      if (c == 0) tri = w0 & 0xffffffu;
+      else if (c == 1) tri = (w0 >> 24) | ((w1 & 0xffffu) << 8);
+      else if (c == 2) tri = (w1 >> 16) | ((w2 & 0xffu) << 16);
+      else tri = w2 >> 8;
+      int v0 = (int)(int8_t)(tri & 0xff);
+      bool same = ((tri >> 8) & 0xff) == (tri & 0xff) && ((tri >> 16) & 0xff) == (tri & 0xff);
+      if (same && v0 != SKYJO_HAND_NONE && v0 != SKYJO_REFUNDED) {
+        for (int k = 0; k < 3; k++) {
+          LB(cardb + 3 * c + k) = (uint8_t)(int8_t)SKYJO_REFUNDED;
+          LB(visb + 3 * c + k) = (uint8_t)(int8_t)SKYJO_REFUNDED;
+          // skyjo.py:454-458: the slice appended to the discard pile is the zeroed MASK -> three 0s
+          LB(pb + pile_addr(reg, ns)) = 0;
+          ns++;
+        }
+        LB(H_HIST + 2) += 3;
+        if (!INDIRECT) LB(H_HIST + 2 + v0) -= 3;
+        sum -= 3 * v0;
+        top = 0;
+        any = true;
+      }
+    }
+    if (any) LB(P.L.off_refunded + p)++;  // +1 per action, not per column (skyjo.py:418-419)
+  }
+  LSH(P.L.off_sums + 2 * p) = (int16_t)sum;
+  LH(P.L.off_placed + 2 * p)++;
+  LB(H_NDISC) = (uint8_t)ns;
+  LB(H_TOP) = (uint8_t)top;
+  LB(H_HAND) = SKYJO_HAND_NONE;
+  LB(H_PHASE) = 0;
+  LB(H_PLAYER) = (uint8_t)(p + 1 == N ? 0 : p + 1);  // skyjo.py:114-120,142-144
+  refresh_minima(P, lp);
+}
+
+// ------------------------------------------------------------------------------------------
+// collect_observation (skyjo.py:148-199) + action mask (skyjo.py:201-224) -> output record.
+// obs[0..18] are a straight copy of state bytes 16..34; the card part is the observer's `vis`
+// row (indirect) or all rows in absolute seat order (direct, skyjo.py:279-302).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t swar_nonzero01(uint32_t x) {
+  return ((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u) >> 7;
+}
+
+template <bool INDIRECT>
+__device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, int q, uint8_t *out) {
+  const int phase = LB(H_PHASE);
+  const int vq = (P.L.off_vis + 12 * q) >> 2;
+  const uint32_t q0 = LW(vq), q1 = LW(vq + 1), q2 = LW(vq + 2);
+  uint32_t m[8];
+  {
+    const uint32_t pm = phase ? 0xffffffffu : 0u;
+    m[0] = swar_nonzero01(q0 ^ 0xf2f2f2f2u) & pm;  // vis != -14  <=> players_masked != 0
+    m[1] = swar_nonzero01(q1 ^ 0xf2f2f2f2u) & pm;
+    m[2] = swar_nonzero01(q2 ^ 0xf2f2f2f2u) & pm;
+    m[3] = (swar_nonzero01(q0 ^ 0x0f0f0f0fu) ^ 0x01010101u) & pm;  // vis == 15 <=> players_masked == 2
+    m[4] = (swar_nonzero01(q1 ^ 0x0f0f0f0fu) ^ 0x01010101u) & pm;
+    m[5] = (swar_nonzero01(q2 ^ 0x0f0f0f0fu) ^ 0x01010101u) & pm;
+    m[6] = (phase ? 0u : 0x0101u) | ((uint32_t)LB(H_PLAYER) << 16) | ((uint32_t)phase << 24);
+    m[7] = ((LB(H_FLAGS) & F_DONE) ? 1u : 0u) | ((uint32_t)LB(H_STATUS) << 8) | ((uint32_t)LH(H_EPLEN) << 16);
+  }
+  const uint32_t s8 = LW(8) & 0x00ffffffu;
+  if (INDIRECT) {
+    uint4 *o = (uint4 *)out;
+    uint4 a, b;
+    a.x = LW(4), a.y = LW(5), a.z = LW(6), a.w = LW(7);
+    b.x = s8 | (q0 << 24), b.y = (q0 >> 8) | (q1 << 24), b.z = (q1 >> 8) | (q2 << 24), b.w = q2 >> 8;
+    o[0] = a, o[1] = b;
+    o[2] = make_uint4(m[0], m[1], m[2], m[3]);
+    o[3] = make_uint4(m[4], m[5], m[6], m[7]);
+  } else {
+    uint32_t *o = (uint32_t *)out;
+    const int nv = 3 * P.L.N, v0 = P.L.off_vis >> 2;
+    for (int w = 0; w < 4; w++) o[w] = LW(4 + w);
+    uint32_t prev = LW(v0);
+    o[4] = s8 | (prev << 24);
+    for (int j = 0; j < nv; j++) {
+      uint32_t nxt = j + 1 < nv ? LW(v0 + j + 1) : 0u;
+      o[5 + j] = (prev >> 8) | (nxt << 24);
+      prev = nxt;
+    }
+    uint32_t *om = o + (P.L.Dp >> 2);
+#pragma unroll
+    for (int w = 0; w < 8; w++) om[w] = m[w];
+  }
+}
+
+// uniform choice over the legal actions == policy_ra's p = mask / sum(mask)
+// (rlskyjo/models/random_admissible_policy.py:26-28); word = Philox4x32-10 output for this
+// (game, iteration), k = mulhi(word, n_legal), action = k-th legal action in ascending order.
+__device__ __forceinline__ int policy_pick(const SkParams &P, uint8_t *lp, uint32_t word) {
+  if (LB(H_PHASE) == 0) return 24 + (int)__umulhi(word, 2u);
+  const int vq = (P.L.off_vis + 12 * LB(H_PLAYER)) >> 2;
+  const uint32_t q0 = LW(vq), q1 = LW(vq + 1), q2 = LW(vq + 2);
+  auto pack = [](uint32_t a, uint32_t b, uint32_t c) -> uint32_t {  // 0/1 bytes -> 12 bits
+    uint32_t r = 0;
+    r |= (a * 0x00204081u >> 21) & 0xfu;  // gather bit0 of each byte: b0 | b8>>7 | b16>>14 | b24>>21
+    r |= ((b * 0x00204081u >> 21) & 0xfu) << 4;
+    r |= ((c * 0x00204081u >> 21) & 0xfu) << 8;
+    return r;
+  };
+  uint32_t legal = pack(swar_nonzero01(q0 ^ 0xf2f2f2f2u), swar_nonzero01(q1 ^ 0xf2f2f2f2u),
+                        swar_nonzero01(q2 ^ 0xf2f2f2f2u)) |
+                   (pack(swar_nonzero01(q0 ^ 0x0f0f0f0fu) ^ 0x01010101u, swar_nonzero01(q1 ^ 0x0f0f0f0fu) ^ 0x01010101u,
+                         swar_nonzero01(q2 ^ 0x0f0f0f0fu) ^ 0x01010101u)
+                    << 12);
+  const int n = __popc(legal);
+  if (n == 0) return 24;
+  int k = (int)__umulhi(word, (uint32_t)n);
+  for (; k > 0; k--) legal &= legal - 1;
+  return __ffs((int)legal) - 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Take the pre-dealt next episode (SkyjoGame.reset, skyjo.py:52-74; the dealing itself is k_deal).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, int tile, int lane, int g,
+                                              int list_sel) {
+  if (!P.spare_ready[g]) return false;
+  tile_load(P, P.spare, tile, lane, lp);
+  P.spare_ready[g] = 0;
+  P.rng_sel[g] ^= 1;
+  P.deals_consumed[g]++;
+  P.done[g] = 0;
+  refill_request(P, g, list_sel);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_step: `iters` lockstep iterations over all tiles.  POLICY=false: one iteration with the
+// caller's actions (SimpleSkyjoEnv.step); POLICY=true: on-device random admissible policy.
+// ------------------------------------------------------------------------------------------
+template <bool INDIRECT, bool POLICY>
+__global__ __launch_bounds__(SK_TILE) void k_step(SkParams P, const int32_t *actions, uint8_t *rec_out,
+                                                  int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0,
+                                                  int list_sel) {
+  extern __shared__ uint32_t lds_raw[];
+  const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
+  uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
+  tile_load(P, P.state, tile, lane, lp);
+  const bool valid = (LB(H_FLAGS) & F_VALID) != 0;
+  LaneCounters cnt;
+  uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+  const uint64_t gid = P.game_id0 + (uint64_t)g;
+  for (int it = 0; it < iters; it++) {
+    const uint64_t iter = iter0 + (uint64_t)it;
+    if (POLICY && (it == 0 || (iter & 3) == 0))
+      philox4x32_10((uint32_t)(iter >> 2), (uint32_t)gid, (uint32_t)(gid >> 32), 0x504F4C00u, (uint32_t)policy_seed,
+                    (uint32_t)(policy_seed >> 32), r0, r1, r2, r3);
+    int a = -1;
+    if (valid) {
+      if (LB(H_FLAGS) & F_DONE) {
+        if (P.auto_reset) {
+          if (consume_spare(P, lp, tile, lane, g, list_sel)) {
+            LB(H_STATUS) = SKYJO_ST_RESET;
+            cnt.resets++;
+          } else {
+            LB(H_STATUS) = SKYJO_ST_WAIT;
+            cnt.waits++;
+          }
+        } else {
+          LB(H_STATUS) = SKYJO_ST_NOOP_DONE;
+        }
+      } else {
+        if (POLICY) {
+          const uint32_t sel = (uint32_t)(iter & 3);
+          a = policy_pick(P, lp, sel == 0 ? r0 : sel == 1 ? r1 : sel == 2 ? r2 : r3);
+        } else {
+          a = actions[g];
+        }
+        apply_action<INDIRECT>(P, lp, a, g, list_sel, cnt);
+      }
+      if (rec_out)
+        emit_record<INDIRECT>(P, lp, LB(H_PLAYER), rec_out + ((size_t)it * P.B + g) * (size_t)P.L.rec_bytes);
+      if (act_out) act_out[(size_t)it * P.B + g] = a;
+    }
+  }
+  tile_store(P, P.state, tile, lane, lp);
+  // one atomic per counter per wave
+  uint32_t v[7] = {cnt.steps, cnt.episodes, cnt.illegal, cnt.resets, cnt.sum_len, cnt.reshuffles, cnt.waits};
+#pragma unroll
+  for (int k = 0; k < 7; k++)
+    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+  if (lane == 0) {
+    unsigned long long *c = &P.counters->steps;
+    if (v[0]) atomicAdd(&c[0], (unsigned long long)v[0]);
+    if (v[1]) atomicAdd(&c[1], (unsigned long long)v[1]);
+    if (v[2]) atomicAdd(&c[2], (unsigned long long)v[2]);
+    if (v[3]) atomicAdd(&c[3], (unsigned long long)v[3]);
+    if (v[4]) atomicAdd(&c[4], (unsigned long long)v[4]);
+    if (v[5]) atomicAdd(&c[5], (unsigned long long)v[5]);
+    if (v[6]) atomicAdd(&c[7], (unsigned long long)v[6]);
+    if (tile == 0) atomicAdd(&c[6], (unsigned long long)iters);
+  }
+}
+
+// SimpleSkyjoEnv.observe(agent) (skyjo_env.py:199-214) for arbitrary players; state untouched.
+template <bool INDIRECT>
+__global__ __launch_bounds__(SK_TILE) void k_observe(SkParams P, const int32_t *players, uint8_t *rec_out) {
+  extern __shared__ uint32_t lds_raw[];
+  const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
+  uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
+  tile_load(P, P.state, tile, lane, lp);
+  if (!(LB(H_FLAGS) & F_VALID)) return;
+  int q = players ? players[g] : LB(H_PLAYER);
+  q = q < 0 ? 0 : (q >= P.L.N ? P.L.N - 1 : q);
+  emit_record<INDIRECT>(P, lp, q, rec_out + (size_t)g * P.L.rec_bytes);
+}
+
+// SkyjoGame.reset for the masked games: take the pre-dealt episode.
+template <bool INDIRECT>
+__global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *mask, uint8_t *rec_out, int list_sel) {
+  extern __shared__ uint32_t lds_raw[];
+  const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
+  uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
+  if (g >= P.B) return;
+  const bool want = !mask || mask[g];
+  bool took = false;
+  if (want) {
+    took = consume_spare(P, lp, tile, lane, g, list_sel);
+    if (took) {
+      LB(H_STATUS) = SKYJO_ST_RESET;
+      atomicAdd(&P.counters->resets, 1ull);
+    }
+  }
+  if (!took) tile_load(P, P.state, tile, lane, lp);
+  if (want && !took) LB(H_STATUS) = SKYJO_ST_WAIT;
+  if (rec_out) emit_record<INDIRECT>(P, lp, LB(H_PLAYER), rec_out + (size_t)g * P.L.rec_bytes);
+  if (want) tile_store(P, P.state, tile, lane, lp);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_seed: np.random.seed(value + 1) per game (skyjo.py:84-94; legacy init_genrand)
+// ------------------------------------------------------------------------------------------
+__global__ void k_seed(SkParams P, const uint64_t *seeds, uint64_t base, int first, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int g = first + i;
+  const uint64_t value = seeds ? seeds[i] : base + P.game_id0 + (uint64_t)g;
+  const size_t G = (size_t)P.tiles * SK_TILE;
+  P.seeds[g] = value;
+  P.rng_sel[g] = 0;
+  P.deals_consumed[g] = 0;
+  P.spare_ready[g] = 0;
+  if (P.rng_mode == SKYJO_RNG_MT19937) {
+    uint32_t *mt = P.mt + (size_t)g * 624;
+    uint32_t x = (uint32_t)(value + 1);
+    mt[0] = x;
+    for (int k = 1; k < 624; k++) {
+      x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)k;
+      mt[k] = x;
+    }
+    P.mt_idx[g] = 624;
+    P.mt_idx[G + g] = 624;
+  }
+}
+
+// np.random.seed(value) on the CURRENT stream of one game, no +1, no deal (fixture injection)
+__global__ void k_seed_raw(SkParams P, int g, uint32_t value) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const size_t G = (size_t)P.tiles * SK_TILE;
+  const int sel = P.rng_sel[g];
+  uint32_t *mt = P.mt + ((size_t)sel * G + g) * 624;
+  uint32_t x = value;
+  mt[0] = x;
+  for (int k = 1; k < 624; k++) {
+    x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)k;
+    mt[k] = x;
+  }
+  P.mt_idx[(size_t)sel * G + g] = 624;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_deal: SkyjoGame.reset's dealing (skyjo.py:52-74 with :76-82, :96-103, :105-125, :127-138) for
+// the games in the refill list, one lane per game, written to the game's SPARE record.
+// RNG order per deal: shuffle(150) -> shuffle(150-12N) -> N x permutation(12)[:2].
+// ------------------------------------------------------------------------------------------
+template <class Rng>
+__device__ __forceinline__ void shuffle_lds(uint8_t *lp, int base, int n, Rng &r) {
+  for (int i = n - 1; i >= 1; i--) {
+    int j = (int)rng_interval(r, (uint32_t)i);
+    uint8_t t = LB(base + i);
+    LB(base + i) = LB(base + j), LB(base + j) = t;
+  }
+}
+
+template <class Rng>
+__device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rng &r, uint32_t episode) {
+  const int N = P.L.N, pb = P.L.off_pile, R = SK_NCARDS - 12 * N;
+  for (int w = 0; w < P.L.chunks * 4; w++) LW(w) = 0;
+  // _new_drawpile: repeat(arange(-2, 13), 10) then shuffle (skyjo.py:76-82)
+  for (int i = 0; i < SK_NCARDS; i++) LB(pb + i) = (uint8_t)(int8_t)(-2 + i / 10);
+  shuffle_lds(lp, pb, SK_NCARDS, r);
+  // first 12N cards row-major to players 0..N-1 (skyjo.py:63-65)
+  for (int i = 0; i < 12 * N; i++) LB(P.L.off_cards + i) = LB(pb + i);
+  // the rest is shuffled again; all but its last card form the draw pile (skyjo.py:68-70,127-138)
+  for (int i = 0; i < R; i++) LB(pb + i) = LB(pb + 12 * N + i);
+  shuffle_lds(lp, pb, R, r);
+  // _reset_card_mask: two open cards per player = permutation(12)[:2] (skyjo.py:96-103)
+  const int tmp = pb + R;  // 12 free bytes behind the rest (R + 12 <= 150)
+  for (int p = 0; p < N; p++) {
+    for (int k = 0; k < 12; k++) LB(tmp + k) = (uint8_t)k, LB(P.L.off_vis + 12 * p + k) = SKYJO_HAND_NONE;
+    shuffle_lds(lp, tmp, 12, r);
+    int s0 = LB(tmp), s1 = LB(tmp + 1);
+    int c0 = LI(P.L.off_cards + 12 * p + s0), c1 = LI(P.L.off_cards + 12 * p + s1);
+    LB(P.L.off_vis + 12 * p + s0) = (uint8_t)c0, LB(P.L.off_vis + 12 * p + s1) = (uint8_t)c1;
+    LSH(P.L.off_sums + 2 * p) = (int16_t)(c0 + c1);
+    LB(P.L.off_hidden + p) = 10;
+    if (!P.L.indirect) LB(H_HIST + 2 + c0)++, LB(H_HIST + 2 + c1)++;
+  }
+  for (int k = R; k < SK_NCARDS; k++) LB(pb + k) = 0;
+  const int last = LI(pb + R - 1);
+  LB(pb + R - 1) = 0;
+  LB(pb + SK_NCARDS - 1) = (uint8_t)last;  // discard pile = [last], stored from the far end
+  LB(H_HIST + 2 + last)++;
+  // _reset_start_player: first argmax of revealed sums draws first (skyjo.py:105-125)
+  int best = 0, bs = LSH(P.L.off_sums);
+  for (int p = 1; p < N; p++) {
+    int s = LSH(P.L.off_sums + 2 * p);
+    if (s > bs) bs = s, best = p;
+  }
+  LB(H_PHASE) = 0, LB(H_PLAYER) = (uint8_t)best, LB(H_FLAGS) = F_VALID, LB(H_STATUS) = SKYJO_ST_RESET;
+  LB(H_NDRAW) = (uint8_t)(R - 1), LB(H_NDISC) = 1, LB(H_ROLE) = 0;
+  LB(H_TOP) = (uint8_t)last, LB(H_HAND) = SKYJO_HAND_NONE;
+  *(uint32_t *)(lp + LIDX(H_EPISODE)) = episode;
+  refresh_minima(P, lp);
+}
+
+__global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int all) {
+  extern __shared__ uint32_t lds_raw[];
+  const int lane = threadIdx.x;
+  uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
+  const size_t G = (size_t)P.tiles * SK_TILE;
+  const int count = all ? P.B : (int)P.refill_count[list_sel];
+  const int32_t *list = P.refill_list + (size_t)list_sel * G;
+  for (int base = blockIdx.x * SK_TILE; base < count; base += gridDim.x * SK_TILE) {
+    const int i = base + lane;
+    const bool act = i < count;
+    const int g = act ? (all ? i : list[i]) : 0;
+    if (P.rng_mode == SKYJO_RNG_MT19937) {
+      // continue the game's stream in the OTHER buffer, so a mid-game reshuffle of the live episode
+      // can still advance the current one and have this deal redone (reshuffle_dispatch)
+      const int sel = act ? P.rng_sel[g] : 0;
+      const unsigned long long src = (unsigned long long)(P.mt + ((size_t)sel * G + g) * 624);
+      const unsigned long long dst = (unsigned long long)(P.mt + ((size_t)(sel ^ 1) * G + g) * 624);
+      for (int l = 0; l < SK_TILE; l++) {  // cooperative, coalesced copy of one 2496-byte state per step
+        if (base + l >= count) break;
+        const uint32_t *s = (const uint32_t *)__shfl(src, l, 64);
+        uint32_t *d = (uint32_t *)__shfl(dst, l, 64);
+        for (int k = lane; k < 624; k += SK_TILE) d[k] = s[k];
+      }
+      __syncthreads();
+      if (act) {
+        MtStream r{(uint32_t *)dst, P.mt_idx[(size_t)sel * G + g]};
+        deal_into_lds(P, lp, r, P.deals_consumed[g]);
+        P.mt_idx[(size_t)(sel ^ 1) * G + g] = r.idx;
+      }
+    } else if (act) {
+      PhiloxStream r;
+      const uint32_t ep = P.deals_consumed[g];
+      r.open(P.seeds[g] + 1, ep, 0u, 0u);
+      deal_into_lds(P, lp, r, ep);
+    }
+    if (act) {
+      tile_store(P, P.spare, g / SK_TILE, g % SK_TILE, lp);
+      P.spare_ready[g] = 1;
+    }
+  }
+  if (!all && blockIdx.x == 0 && lane == 0) P.refill_count[list_sel ^ 1] = 0;
+}
+
+// records -> the reference's dense arrays (obs int8[n][D], mask int8[n][26], ...)
+__global__ void k_unpack(SkLayout L, const uint8_t *rec, long long n, int8_t *obs, int8_t *mask, uint8_t *agent,
+                         uint8_t *phase, uint8_t *done, uint8_t *status) {
+  const long long total = n * (long long)(L.D + 26);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / (L.D + 26);
+    const int k = (int)(i % (L.D + 26));
+    const uint8_t *src = rec + r * L.rec_bytes;
+    if (k < L.D) {
+      if (obs) obs[r * L.D + k] = (int8_t)src[k];
+    } else {
+      if (mask) mask[r * 26 + (k - L.D)] = (int8_t)src[L.Dp + (k - L.D)];
+    }
+    if (k == 0) {
+      if (agent) agent[r] = src[L.Dp + 26];
+      if (phase) phase[r] = src[L.Dp + 27];
+      if (done) done[r] = src[L.Dp + 28];
+      if (status) status[r] = src[L.Dp + 29];
+    }
+  }
+}

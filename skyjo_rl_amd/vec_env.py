@@ -1,0 +1,277 @@
+"""SkyjoVecEnv - batched SkyJo games on one MI355X through the C ABI of libskyjo_vec.so.
+
+The class is a thin owner of a native handle.  Two call styles:
+
+* device style (torch tensors on the GPU, zero host traffic): ``step(actions)``, ``rollout(k)``,
+  ``observe()``, ``reset()`` return the raw output records as a ``torch.uint8`` tensor
+  ``[..., record_bytes]``; ``split(records)`` gives zero-copy strided views named like the
+  reference's observation dict (``observations`` int8[..., D], ``action_mask`` int8[..., 26],
+  rlskyjo/environment/skyjo_env.py:199-214) plus ``agent``, ``phase``, ``done``, ``status``.
+* host style (numpy, synchronous; used by the single-game AEC / SkyjoGame views):
+  ``step_host``, ``observe_host``, ``reset_host``, ``rewards_host``.
+
+There is no CPU implementation behind this class: construction fails without the HIP library
+and a gfx950 device.
+"""
+import collections
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+Obs = collections.namedtuple("Obs", "observations action_mask agent phase done status episode_steps")
+
+
+def split_records_np(rec, obs_dim):
+    """Strided numpy views into host records [..., record_bytes] (layout: include/skyjo_vec.h)."""
+    rec = np.asarray(rec)
+    dp = (obs_dim + 3) & ~3
+    i8 = rec.view(np.int8)
+    steps = rec[..., dp + 30].astype(np.uint16) | (rec[..., dp + 31].astype(np.uint16) << 8)
+    return Obs(i8[..., :obs_dim], i8[..., dp:dp + 26], rec[..., dp + 26], rec[..., dp + 27], rec[..., dp + 28],
+               rec[..., dp + 29], steps)
+
+
+class SkyjoVecEnv:
+    def __init__(self, num_envs, num_players=3, score_penalty=2.0, observe_other_player_indirect=True,
+                 mean_reward=1.0, reward_refunded=0.001, device=0, rng_mode=_lib.RNG_MT19937, auto_reset=True,
+                 game_id0=0, illegal_reward=-1.0):
+        # same precondition and message as rlskyjo/game/skyjo.py:24-26
+        assert 0 < num_players <= 12, "Skyjo can be played from 1 up to 8 (recommended) / 12 (theoretical) players"
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        cfg = _lib.Config(_lib.ABI_VERSION, int(num_envs), int(num_players), int(bool(observe_other_player_indirect)),
+                          float(score_penalty), float(mean_reward), float(reward_refunded), float(illegal_reward),
+                          int(device), int(rng_mode), int(bool(auto_reset)), 0, int(game_id0))
+        _lib.check(self._L.skyjo_vec_create(C.byref(cfg), C.byref(self._h)))
+        info = _lib.Info()
+        _lib.check(self._L.skyjo_vec_get_info(self._h, C.byref(info)))
+        self.num_envs, self.num_players = info.num_envs, info.num_players
+        self.obs_dim, self.record_bytes = info.obs_dim, info.record_bytes
+        self.mask_offset, self.meta_offset, self.state_bytes = info.mask_offset, info.meta_offset, info.state_bytes
+        self.device_index = int(device)
+        self.rng_mode, self.auto_reset = int(rng_mode), bool(auto_reset)
+        self.game_id0 = int(game_id0)
+        self.obs_shape = (self.obs_dim,)       # skyjo.py:43-45
+        self.action_mask_shape = (26,)         # skyjo.py:46
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.skyjo_vec_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ torch plumbing
+    @staticmethod
+    def _torch():
+        import torch
+        return torch
+
+    def _stream(self):
+        torch = self._torch()
+        return C.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream)
+
+    def _dev(self):
+        return self._torch().device("cuda", self.device_index)
+
+    def new_records(self, *lead):
+        return self._torch().empty((*lead, self.num_envs, self.record_bytes), dtype=self._torch().uint8,
+                                   device=self._dev())
+
+    def split(self, records):
+        """Zero-copy views of a records tensor: the reference's {"observations","action_mask"} + meta."""
+        torch = self._torch()
+        dp = self.mask_offset
+        i8 = records.view(torch.int8)
+        steps = records[..., dp + 30].to(torch.int32) | (records[..., dp + 31].to(torch.int32) << 8)
+        return Obs(i8[..., :self.obs_dim], i8[..., dp:dp + 26], records[..., dp + 26], records[..., dp + 27],
+                   records[..., dp + 28], records[..., dp + 29], steps)
+
+    # ------------------------------------------------------------------ device style API
+    def seed(self, seeds=None, base_seed=0):
+        """SkyjoGame.set_seed per game (skyjo.py:84-88): game i <- seeds[i] (default base_seed + game id)."""
+        ptr = None
+        if seeds is not None:
+            seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+            assert seeds.shape == (self.num_envs,)
+            ptr = seeds.ctypes.data_as(C.c_void_p)
+        _lib.check(self._L.skyjo_vec_seed(self._h, ptr, int(base_seed), None))
+        _lib.check(self._L.skyjo_dev_sync(None))
+
+    def reset(self, mask=None, out=None):
+        torch = self._torch()
+        out = self.new_records() if out is None else out
+        mp = None
+        if mask is not None:
+            mask = mask.to(device=self._dev(), dtype=torch.uint8).contiguous()
+            mp = C.c_void_p(mask.data_ptr())
+        _lib.check(self._L.skyjo_vec_reset(self._h, mp, C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def step(self, actions, out=None):
+        """SimpleSkyjoEnv.step for every game (skyjo_env.py:216-252); actions: int32 cuda tensor [num_envs]."""
+        torch = self._torch()
+        assert actions.is_cuda and actions.dtype == torch.int32 and actions.is_contiguous()
+        assert actions.numel() == self.num_envs
+        out = self.new_records() if out is None else out
+        _lib.check(self._L.skyjo_vec_step(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(out.data_ptr()),
+                                          self._stream()))
+        return out
+
+    def rollout(self, iters, policy_seed=0, records=None, actions=None):
+        """`iters` lockstep iterations with the on-device random admissible policy.
+
+        records: None or uint8 cuda tensor [iters, num_envs, record_bytes]; actions: None or int32 [iters, num_envs].
+        """
+        rp = C.c_void_p(records.data_ptr()) if records is not None else None
+        ap = C.c_void_p(actions.data_ptr()) if actions is not None else None
+        if records is not None:
+            assert records.is_contiguous() and records.numel() == iters * self.num_envs * self.record_bytes
+        if actions is not None:
+            assert actions.is_contiguous() and actions.numel() == iters * self.num_envs
+        _lib.check(self._L.skyjo_vec_rollout(self._h, int(iters), int(policy_seed), rp, ap, self._stream()))
+
+    def observe(self, players=None, out=None):
+        out = self.new_records() if out is None else out
+        pp = C.c_void_p(players.data_ptr()) if players is not None else None
+        _lib.check(self._L.skyjo_vec_observe(self._h, pp, C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def unpack(self, records):
+        """Dense copies shaped like the reference's arrays: obs int8[n, D], mask int8[n, 26]."""
+        torch = self._torch()
+        n = records.numel() // self.record_bytes
+        obs = torch.empty((n, self.obs_dim), dtype=torch.int8, device=self._dev())
+        mask = torch.empty((n, 26), dtype=torch.int8, device=self._dev())
+        _lib.check(self._L.skyjo_vec_unpack(self._h, C.c_void_p(records.data_ptr()), n, C.c_void_p(obs.data_ptr()),
+                                            C.c_void_p(mask.data_ptr()), None, None, None, None, self._stream()))
+        return obs, mask
+
+    def rewards_tensor(self):
+        torch = self._torch()
+        out = torch.empty((self.num_envs, self.num_players), dtype=torch.float64, device=self._dev())
+        src = self._L.skyjo_vec_rewards_ptr(self._h)
+        _lib.check(self._L.skyjo_dev_copy(C.c_void_p(out.data_ptr()), C.c_void_p(src), out.numel() * 8, 3,
+                                          self._stream()))
+        return out
+
+    def sync(self):
+        _lib.check(self._L.skyjo_dev_sync(None))
+
+    # ------------------------------------------------------------------ host style API
+    def _host_records(self):
+        return np.zeros((self.num_envs, self.record_bytes), dtype=np.uint8)
+
+    def step_host(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        assert a.shape == (self.num_envs,)
+        rec = self._host_records()
+        _lib.check(self._L.skyjo_vec_step_host(self._h, a.ctypes.data_as(C.c_void_p), rec.ctypes.data_as(C.c_void_p)))
+        return split_records_np(rec, self.obs_dim)
+
+    def observe_host(self, players=None):
+        rec = self._host_records()
+        pp = None
+        if players is not None:
+            players = np.ascontiguousarray(players, dtype=np.int32)
+            pp = players.ctypes.data_as(C.c_void_p)
+        _lib.check(self._L.skyjo_vec_observe_host(self._h, pp, rec.ctypes.data_as(C.c_void_p)))
+        return split_records_np(rec, self.obs_dim)
+
+    def reset_host(self, mask=None):
+        rec = self._host_records()
+        mp = None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            mp = mask.ctypes.data_as(C.c_void_p)
+        _lib.check(self._L.skyjo_vec_reset_host(self._h, mp, rec.ctypes.data_as(C.c_void_p)))
+        return split_records_np(rec, self.obs_dim)
+
+    def rewards_host(self):
+        rew = np.zeros((self.num_envs, self.num_players), dtype=np.float64)
+        sc = np.zeros((self.num_envs, self.num_players), dtype=np.float64)
+        done = np.zeros(self.num_envs, dtype=np.uint8)
+        _lib.check(self._L.skyjo_vec_get_rewards_host(self._h, rew.ctypes.data_as(C.c_void_p),
+                                                      sc.ctypes.data_as(C.c_void_p), done.ctypes.data_as(C.c_void_p)))
+        return rew, sc, done
+
+    def rollout_host(self, iters, policy_seed=0):
+        """rollout without recording (counters only), synchronous."""
+        _lib.check(self._L.skyjo_vec_rollout(self._h, int(iters), int(policy_seed), None, None, None))
+        _lib.check(self._L.skyjo_dev_sync(None))
+
+    # ------------------------------------------------------------------ counters / state
+    def counters(self):
+        c = _lib.Counters()
+        _lib.check(self._L.skyjo_vec_get_counters(self._h, C.byref(c), None))
+        N = self.num_players
+        return dict(steps=c.steps, episodes=c.episodes, illegal=c.illegal, resets=c.resets, sum_len=c.sum_len,
+                    reshuffles=c.reshuffles, iters=c.iters, waits=c.waits,
+                    sum_score=np.array(c.sum_score[:N]), sum_reward=np.array(c.sum_reward[:N]))
+
+    def profile(self, enable):
+        """Collect-and-clear HIP-event timings of the kernels launched since the last call (bench roofline leg)."""
+        sm, dm = C.c_double(), C.c_double()
+        sl, dl = C.c_int64(), C.c_int64()
+        _lib.check(self._L.skyjo_vec_profile(self._h, int(bool(enable)), C.byref(sm), C.byref(sl), C.byref(dm),
+                                             C.byref(dl)))
+        return dict(step_ms=sm.value, step_launches=sl.value, deal_ms=dm.value, deal_launches=dl.value)
+
+    def set_deal_interval(self, n):
+        _lib.check(self._L.skyjo_vec_set_option(self._h, 1, int(n)))
+
+    def reset_counters(self):
+        _lib.check(self._L.skyjo_vec_reset_counters(self._h, None))
+
+    def get_state(self, game):
+        s = _lib.GameState()
+        _lib.check(self._L.skyjo_vec_get_state(self._h, int(game), C.byref(s), None))
+        N = self.num_players
+        return dict(
+            cards=np.array([list(s.players_cards[p]) for p in range(N)], dtype=np.int8),
+            masked=np.array([list(s.players_masked[p]) for p in range(N)], dtype=np.int8),
+            draw=np.array(list(s.drawpile[: s.n_draw]), dtype=np.int8), n_draw=int(s.n_draw),
+            disc=np.array(list(s.discard_pile[: s.n_disc]), dtype=np.int8), n_disc=int(s.n_disc),
+            hand=int(s.hand_card), player=int(s.expected_player), phase=int(s.expected_phase),
+            is_terminated=bool(s.is_terminated), done=bool(s.done), status=int(s.status),
+            episode_steps=int(s.episode_steps), episode=int(s.episode), reshuffles=int(s.reshuffles),
+            num_refunded=np.array(s.num_refunded[:N], dtype=np.int32),
+            num_placed=np.array(s.num_placed[:N], dtype=np.int32),
+            final_score=np.array(s.final_score[:N], dtype=np.float64),
+            rewards=np.array(s.rewards[:N], dtype=np.float64))
+
+    def set_state(self, game, cards, masked, draw, disc, hand=15, player=0, phase=0, num_refunded=None,
+                  num_placed=None, episode=0):
+        """Fixture injection / restore: overwrite one live game (the RNG streams are left untouched)."""
+        s = _lib.GameState()
+        N = self.num_players
+        cards = np.asarray(cards, dtype=np.int8).reshape(N, 12)
+        masked = np.asarray(masked, dtype=np.int8).reshape(N, 12)
+        for p in range(N):
+            for k in range(12):
+                s.players_cards[p][k] = int(cards[p, k])
+                s.players_masked[p][k] = int(masked[p, k])
+        draw, disc = np.asarray(draw, dtype=np.int8).ravel(), np.asarray(disc, dtype=np.int8).ravel()
+        for k, c in enumerate(draw):
+            s.drawpile[k] = int(c)
+        for k, c in enumerate(disc):
+            s.discard_pile[k] = int(c)
+        s.n_draw, s.n_disc = len(draw), len(disc)
+        s.hand_card, s.expected_player, s.expected_phase = int(hand), int(player), int(phase)
+        s.episode = int(episode)
+        for p in range(N):
+            s.num_refunded[p] = int(num_refunded[p]) if num_refunded is not None else 0
+            s.num_placed[p] = int(num_placed[p]) if num_placed is not None else 0
+        _lib.check(self._L.skyjo_vec_set_state(self._h, int(game), C.byref(s), None))
+
+    def seed_raw(self, game, value):
+        """np.random.seed(value) on one game's legacy stream, no deal (fixtures)."""
+        _lib.check(self._L.skyjo_vec_seed_raw(self._h, int(game), int(value) & 0xFFFFFFFF, None))
+        _lib.check(self._L.skyjo_dev_sync(None))

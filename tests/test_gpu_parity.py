@@ -1,0 +1,251 @@
+"""GPU parity: the HIP engine (through the C ABI) vs golden vectors from the reference and vs the
+pinned CPU oracle on identical seeded inputs.  Integer / byte work: every comparison is bit-exact;
+float64 scores and rewards are compared with == as well (same operation order, no FMA)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TRAJ = sorted(glob.glob(os.path.join(GOLDEN, "traj_*.npz")) + glob.glob(os.path.join(GOLDEN, "dense_*.npz")))
+REWARD_CFGS = [(1.0, 0.001), (0.0, 0.0), (-1.0, 0.01), (1.0, 0.0)]
+
+
+def _engine(*a, **k):
+    from skyjo_rl_amd import SkyjoVecEnv
+    return SkyjoVecEnv(*a, **k)
+
+
+def _cmp_state(s, d, prefix, e):
+    np.testing.assert_array_equal(s["cards"], d[prefix + "cards"][e])
+    np.testing.assert_array_equal(s["masked"], d[prefix + "masked"][e])
+    assert s["n_draw"] == d[prefix + "n_draw"][e] and s["n_disc"] == d[prefix + "n_disc"][e]
+    np.testing.assert_array_equal(s["draw"], d[prefix + "draw"][e][: s["n_draw"]])
+    np.testing.assert_array_equal(s["disc"], d[prefix + "disc"][e][: s["n_disc"]])
+    assert (s["hand"], s["player"], s["phase"]) == (d[prefix + "hand"][e], d[prefix + "player"][e], d[prefix + "phase"][e])
+
+
+@pytest.mark.parametrize("path", TRAJ, ids=[os.path.basename(p)[:-4] for p in TRAJ])
+def test_golden_trajectory(path):
+    """Reference trajectories replayed on the GPU: 3 copies of the game, every step bit-equal."""
+    d = np.load(path)
+    N, seed, ind = int(d["num_players"]), int(d["seed"]), bool(d["indirect"])
+    dense = str(d["kind"]) == "dense"
+    B = 3
+    cfg_k = (len(os.path.basename(path)) + seed) % len(REWARD_CFGS)  # spread reward configs over the fixtures
+    mr, rr = REWARD_CFGS[cfg_k]
+    eng = _engine(B, num_players=N, score_penalty=float(d["score_penalty"]), observe_other_player_indirect=ind,
+                  mean_reward=mr, reward_refunded=rr, auto_reset=False)
+    eng.seed(np.full(B, seed, dtype=np.uint64))
+    E = len(d["ep_start"]) - 1
+    for e in range(E):
+        if e > 0:
+            eng.reset_host()
+        if dense:
+            nd, ns = int(d["deal_n_draw"][e]), int(d["deal_n_disc"][e])
+            for i in range(B):
+                eng.set_state(i, d["deal_cards"][e], d["deal_masked"][e], d["deal_draw"][e][:nd],
+                              d["deal_disc"][e][:ns], int(d["deal_hand"][e]), int(d["deal_player"][e]),
+                              int(d["deal_phase"][e]))
+        _cmp_state(eng.get_state(B - 1), d, "deal_", e)
+        o = eng.observe_host()
+        for t in range(int(d["ep_start"][e]), int(d["ep_start"][e + 1])):
+            pid = int(d["player"][t])
+            for i in range(B):
+                assert (o.agent[i], o.phase[i], o.done[i]) == (pid, d["phase"][t], 0), (t, i)
+                np.testing.assert_array_equal(o.observations[i], d["obs"][t], err_msg=f"obs t={t}")
+                np.testing.assert_array_equal(o.action_mask[i], d["mask"][t], err_msg=f"mask t={t}")
+            if t % 7 == 0:  # observe() of a player who is not on turn (skyjo_env.py:199-214)
+                oo = eng.observe_host(np.full(B, (pid + 1) % N, dtype=np.int32))
+                np.testing.assert_array_equal(oo.observations[0], d["obs_other"][t])
+                np.testing.assert_array_equal(oo.action_mask[0], d["mask_other"][t])
+            o = eng.step_host(np.full(B, int(d["action"][t]), dtype=np.int32))
+            assert np.all(o.status == 0)
+            assert np.all(o.done == d["game_over"][t]), t
+        s = eng.get_state(1)
+        assert s["is_terminated"] and s["done"]
+        _cmp_state(s, d, "end_", e)
+        np.testing.assert_array_equal(s["final_score"], d["final_score"][e])
+        np.testing.assert_array_equal(s["num_refunded"], d["num_refunded"][e])
+        np.testing.assert_array_equal(s["num_placed"], d["num_placed"][e])
+        np.testing.assert_array_equal(s["rewards"], d["rewards"][e][cfg_k])
+        rew, sc, done = eng.rewards_host()
+        np.testing.assert_array_equal(rew[0], d["rewards"][e][cfg_k])
+        assert np.all(done == 1)
+        # trap 18: stepping a finished game without auto-reset is a no-op (skyjo.py:316-321)
+        o2 = eng.step_host(np.full(B, 24, dtype=np.int32))
+        assert np.all(o2.status == 2) and np.all(o2.done == 1)
+        _cmp_state(eng.get_state(1), d, "end_", e)
+    eng.close()
+
+
+def test_golden_scenarios():
+    d = np.load(os.path.join(GOLDEN, "scenarios.npz"))
+    for name in d["names"]:
+        p = str(name) + "/"
+        N, ind, np_seed = (int(x) for x in d[p + "cfg"])
+        eng = _engine(2, num_players=N, score_penalty=float(d[p + "penalty"]), observe_other_player_indirect=bool(ind),
+                      auto_reset=False)
+        eng.seed(None, 5)
+        nd, ns = int(d[p + "init_n_draw"]), int(d[p + "init_n_disc"])
+        for i in range(2):
+            eng.set_state(i, d[p + "init_cards"], d[p + "init_masked"], d[p + "init_draw"][:nd],
+                          d[p + "init_disc"][:ns], int(d[p + "init_hand"]), int(d[p + "init_player"]),
+                          int(d[p + "init_phase"]))
+            if np_seed >= 0:
+                eng.seed_raw(i, np_seed)
+        o = eng.observe_host()
+        for t, a in enumerate(d[p + "actions"]):
+            np.testing.assert_array_equal(o.observations[1], d[p + "step_obs"][t], err_msg=f"{name} obs t={t}")
+            np.testing.assert_array_equal(o.action_mask[1], d[p + "step_mask"][t], err_msg=f"{name} mask t={t}")
+            o = eng.step_host(np.full(2, int(a), dtype=np.int32))
+            assert np.all(o.done == d[p + "step_over"][t]), (name, t)
+            s = eng.get_state(1)
+            np.testing.assert_array_equal(s["cards"], d[p + "step_cards"][t], err_msg=f"{name} t={t}")
+            np.testing.assert_array_equal(s["masked"], d[p + "step_masked"][t], err_msg=f"{name} t={t}")
+            assert s["n_draw"] == d[p + "step_n_draw"][t] and s["n_disc"] == d[p + "step_n_disc"][t], (name, t)
+            np.testing.assert_array_equal(s["draw"], d[p + "step_draw"][t][: s["n_draw"]], err_msg=f"{name} t={t}")
+            np.testing.assert_array_equal(s["disc"], d[p + "step_disc"][t][: s["n_disc"]], err_msg=f"{name} t={t}")
+            assert (s["hand"], s["player"], s["phase"]) == (
+                d[p + "step_hand"][t], d[p + "step_player"][t], d[p + "step_phase"][t]), (name, t)
+        np.testing.assert_array_equal(o.observations[0], d[p + "final_obs"], err_msg=str(name))
+        np.testing.assert_array_equal(o.action_mask[0], d[p + "final_mask"], err_msg=str(name))
+        s = eng.get_state(0)
+        assert s["is_terminated"] == bool(d[p + "terminated"])
+        np.testing.assert_array_equal(s["num_refunded"], d[p + "num_refunded"])
+        np.testing.assert_array_equal(s["num_placed"], d[p + "num_placed"])
+        if s["is_terminated"]:
+            np.testing.assert_array_equal(s["final_score"], d[p + "final_score"])
+            np.testing.assert_array_equal(s["rewards"], d[p + "rewards"][0])  # default reward cfg (1.0, 0.001)
+        eng.close()
+
+
+def _oracle_vec(**k):
+    from oracle import skyjo_oracle as so
+    return so.OracleVec(**k)
+
+
+@pytest.mark.parametrize("N,ind,rng_mode,B", [(2, True, 0, 4096), (3, False, 0, 1000), (12, True, 0, 300),
+                                              (4, True, 1, 1500), (1, False, 1, 200), (8, False, 1, 130)])
+def test_step_vs_oracle_random_actions(N, ind, rng_mode, B):
+    """Lockstep stepping with caller-provided actions (legal, some illegal), auto-reset on."""
+    cfg = dict(num_players=N, score_penalty=2.0, observe_other_player_indirect=ind, mean_reward=1.0,
+               reward_refunded=0.001, rng_mode=rng_mode, auto_reset=True)
+    eng = _engine(B, **cfg)
+    ora = _oracle_vec(num_envs=B, **cfg)
+    eng.seed(None, 1234)
+    ora.seed(None, 1234)
+    rng = np.random.default_rng(7)
+    steps = 700 if N <= 4 else 1500
+    for t in range(steps):
+        obs, mask, agent, phase = ora.observe()
+        o = eng.observe_host()
+        np.testing.assert_array_equal(o.observations, obs, err_msg=f"obs t={t}")
+        np.testing.assert_array_equal(o.action_mask, mask, err_msg=f"mask t={t}")
+        np.testing.assert_array_equal(o.agent, agent)
+        np.testing.assert_array_equal(o.phase, phase)
+        # uniformly random legal action, 0.2 % illegal ones
+        u = rng.random((B, 26)) * mask
+        acts = np.argmax(u, axis=1).astype(np.int32)
+        bad = rng.random(B) < 0.002
+        acts[bad] = rng.integers(-2, 29, size=int(bad.sum()))
+        ora.step(acts)
+        o = eng.step_host(acts)
+        np.testing.assert_array_equal(o.status, ora.status, err_msg=f"status t={t}")
+        np.testing.assert_array_equal(o.done, ora.dones, err_msg=f"done t={t}")
+        rew, sc, done = eng.rewards_host()
+        dn = ora.dones.astype(bool)
+        np.testing.assert_array_equal(rew[dn], ora.rewards[dn], err_msg=f"rewards t={t}")
+    c, oc = eng.counters(), ora.counters()
+    for k in ("steps", "episodes", "illegal", "resets", "sum_len"):
+        assert c[k] == oc[k], (k, c[k], oc[k])
+    assert c["episodes"] > 0 and c["illegal"] > 0
+    eng.close()
+
+
+@pytest.mark.parametrize("N,ind,rng_mode,B", [(3, True, 0, 4096), (2, True, 0, 4096), (4, True, 1, 2048),
+                                              (3, False, 1, 777), (12, True, 0, 128)])
+def test_rollout_vs_oracle(N, ind, rng_mode, B):
+    """Fused K-step rollout kernel with the on-device policy vs the oracle's restatement of it."""
+    import torch
+
+    cfg = dict(num_players=N, score_penalty=2.0, observe_other_player_indirect=ind, mean_reward=1.0,
+               reward_refunded=0.001, rng_mode=rng_mode, auto_reset=True)
+    eng = _engine(B, game_id0=1000, **cfg)
+    ora = _oracle_vec(num_envs=B, game_id0=1000, **cfg)
+    eng.seed(None, 99)
+    ora.seed(None, 99)
+    K, rounds = 40, 12 if N <= 4 else 30
+    for r in range(rounds):
+        rec = eng.new_records(K)
+        act = torch.empty((K, B), dtype=torch.int32, device="cuda")
+        eng.rollout(K, policy_seed=4242, records=rec, actions=act)
+        oact = ora.rollout(K, 4242, record_actions=True)
+        np.testing.assert_array_equal(act.cpu().numpy(), oact, err_msg=f"actions round {r}")
+        last = eng.split(rec[K - 1])
+        obs, mask, agent, phase = ora.observe()
+        np.testing.assert_array_equal(last.observations.cpu().numpy(), obs)
+        np.testing.assert_array_equal(last.action_mask.cpu().numpy(), mask)
+        np.testing.assert_array_equal(last.agent.cpu().numpy(), agent)
+        np.testing.assert_array_equal(last.done.cpu().numpy(), ora.dones)
+        np.testing.assert_array_equal(last.status.cpu().numpy(), ora.status)
+    c, oc = eng.counters(), ora.counters()
+    for k in ("steps", "episodes", "illegal", "resets", "sum_len", "iters"):
+        assert c[k] == oc[k] if k != "iters" else c[k] == oc["iter"], (k, c, oc)
+    assert c["waits"] == 0 and c["illegal"] == 0 and c["episodes"] > B
+    dn = ora.dones.astype(bool)
+    rew, sc, done = eng.rewards_host()
+    np.testing.assert_array_equal(rew[dn], ora.rewards[dn])
+    eng.close()
+
+
+def test_headline_size_properties():
+    """BASELINE config 3 (65 536 three-player games): size-independent invariants + an oracle-checked subset."""
+    import torch
+
+    B, N = 65536, 3
+    cfg = dict(num_players=N, score_penalty=2.0, observe_other_player_indirect=True, mean_reward=1.0,
+               reward_refunded=0.001, rng_mode=0, auto_reset=True)
+    eng = _engine(B, **cfg)
+    eng.seed(None, 0)
+    sub0, subn = 40000, 192  # games 40000..40191 are re-simulated by the oracle from their ids alone
+    ora = _oracle_vec(num_envs=subn, game_id0=sub0, **cfg)
+    ora.seed(None, 0)
+    K = 64
+    for r in range(6):
+        rec = eng.new_records(K)
+        act = torch.empty((K, B), dtype=torch.int32, device="cuda")
+        eng.rollout(K, policy_seed=1, records=rec, actions=act)
+        oact = ora.rollout(K, 1, record_actions=True)
+        np.testing.assert_array_equal(act[:, sub0:sub0 + subn].cpu().numpy(), oact)
+        v = eng.split(rec)
+        # every mask is non-empty for live games and consistent with the phase byte
+        m = v.action_mask.to(torch.int32)
+        live = v.done == 0
+        assert bool(((m.sum(-1) > 0) | ~live).all())
+        draw = v.phase == 0
+        assert bool((m[..., 24:].sum(-1)[draw & live] == 2).all()) and bool((m[..., :24].sum(-1)[draw & live] == 0).all())
+        # observation bounds: Box(-24, 127) (skyjo_env.py:129-133), hand is 15 exactly in the draw phase
+        o = v.observations.to(torch.int32)
+        assert int(o.min()) >= -24
+        assert bool(((o[..., 18] == 15) == draw)[live].all())
+        # histogram of the discard pile never exceeds the deck: 10 per value, + 3 zeros per collapse
+        assert int(o[..., 2:17].max()) <= 10 + 3 * 4 * N
+    c = eng.counters()
+    assert c["steps"] + c["resets"] == 6 * K * B and c["waits"] == 0 and c["illegal"] == 0
+    assert 95 < c["sum_len"] / c["episodes"] < 120  # SURVEY: mean episode length 108 at N=3
+    # finished episodes: sum of rewards over seats == N * mean_reward + refunded bonus (skyjo_env.py:307-312)
+    rew, sc, done = eng.rewards_host()
+    dn = done.astype(bool)
+    assert dn.sum() > 100
+    resid = rew[dn].sum(1) - N * 1.0
+    assert np.all(resid > -1e-9) and np.all(resid < 12 * 0.001 + 1e-9)
+    # card conservation on a sample: cards on the table + piles + hand == 150 - 12N + 3 * collapses
+    for g in (0, 1, 12345, 65535):
+        s = eng.get_state(g)
+        collapsed = int((s["masked"] == 0).sum()) // 3
+        assert s["n_draw"] + s["n_disc"] + (s["hand"] != 15) == 150 - 12 * N + 3 * collapsed
+    eng.close()
