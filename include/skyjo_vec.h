@@ -52,7 +52,7 @@ extern "C" {
 #define SKYJO_ST_ILLEGAL 1   /* action masked out or out of range: TerminateIllegalWrapper semantics */
 #define SKYJO_ST_NOOP_DONE 2 /* game already over and auto_reset off (skyjo.py:316-321) */
 #define SKYJO_ST_RESET 3     /* game was over: a new episode was dealt, the action was ignored */
-#define SKYJO_ST_WAIT 4      /* game over, next deal not ready yet (only with deferred dealing) */
+#define SKYJO_ST_WAIT 4      /* reserved (never produced: a missing pre-dealt episode is dealt in place) */
 
 /* RNG modes */
 #define SKYJO_RNG_MT19937 0 /* numpy legacy stream, bit-identical deals to the reference */
@@ -97,7 +97,7 @@ typedef struct skyjo_vec_counters {
   uint64_t sum_len;  /* sum of episode lengths of finished episodes */
   uint64_t reshuffles;
   uint64_t iters;    /* lockstep iterations executed */
-  uint64_t waits;
+  uint64_t waits;    /* deals made on the in-kernel slow path (pre-dealt episode not available) */
   double sum_score[SKYJO_MAX_PLAYERS];  /* per seat, finished episodes */
   double sum_reward[SKYJO_MAX_PLAYERS]; /* per seat, finished + illegal episodes */
 } skyjo_vec_counters;
@@ -181,7 +181,7 @@ int skyjo_vec_profile(skyjo_vec *h, int enable, double *step_ms, int64_t *step_l
                       int64_t *deal_launches);
 
 /* Tunables.  SKYJO_OPT_DEAL_INTERVAL: skyjo_vec_step launches between two runs of the dealing kernel
- * (1..64, default 1); a finished game whose next deal is not ready yet reports SKYJO_ST_WAIT. */
+ * (1..64, default 1); a finished game whose next deal is not ready yet deals in place (slow path). */
 #define SKYJO_OPT_DEAL_INTERVAL 1
 int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value);
 

@@ -96,6 +96,13 @@ def load():
         raise SkyjoNativeError(
             f"{LIB_PATH} is missing: build it with `python -m skyjo_rl_amd.build` (hipcc, gfx950). "
             "skyjo_rl_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7.  Two HIP runtimes in one process cannot both own the
+    # GPU ("No HIP GPUs are available" in whichever initialises second), so when torch is installed its copy
+    # is loaded first and libskyjo_vec.so binds to that one through the shared SONAME.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:

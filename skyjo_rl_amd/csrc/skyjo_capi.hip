@@ -38,8 +38,7 @@ struct skyjo_vec {
   size_t G = 0;           // tiles * 64
   size_t lds_bytes = 0;
   bool seeded = false;
-  int list_sel = 0;
-  int pending_deals = 0;  // step launches since the refill list was last drained
+  int pending_deals = 0;  // step launches since the dealing kernel last ran
   int deal_interval = 1;
   uint64_t iter = 0;
   // lazily allocated scratch for the *_host conveniences
@@ -81,14 +80,13 @@ int prof_end(skyjo_vec *h, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, hi
 }
 
 int launch_deal(skyjo_vec *h, hipStream_t s, bool all) {
-  int blocks = (int)(h->G / SK_TILE);
-  if (blocks > 512) blocks = 512;
+  const int blocks = (h->P.B + SK_DEAL_SPAN - 1) / SK_DEAL_SPAN;
   int rc;
   if ((rc = prof_begin(h, h->ev_deal, s))) return rc;
-  hipLaunchKernelGGL(k_deal, dim3(blocks), dim3(SK_TILE), h->lds_bytes, s, h->P, h->list_sel, all ? 1 : 0);
+  hipLaunchKernelGGL(k_deal, dim3(blocks), dim3(SK_TILE), h->lds_bytes - 4096 + 16384 + SK_DEAL_SPAN * sizeof(int32_t), s, h->P,
+                     all ? 1 : 0);
   HIPCHK(hipGetLastError());
   if ((rc = prof_end(h, h->ev_deal, s))) return rc;
-  if (!all) h->list_sel ^= 1;
   h->pending_deals = 0;
   return SKYJO_OK;
 }
@@ -99,7 +97,7 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
   const bool ind = h->P.L.indirect != 0;
 #define LAUNCH(I, Pol)                                                                                          \
   hipLaunchKernelGGL((k_step<I, Pol>), grid, block, h->lds_bytes, s, h->P, actions, rec, act_out, iters,       \
-                     policy_seed, h->iter, h->list_sel)
+                     policy_seed, h->iter)
   int prc;
   if ((prc = prof_begin(h, h->ev_step, s))) return prc;
   if (ind && policy) LAUNCH(true, true);
@@ -109,7 +107,7 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
 #undef LAUNCH
   HIPCHK(hipGetLastError());
   if ((prc = prof_end(h, h->ev_step, s))) return prc;
-  h->iter += (uint64_t)iters;
+  if (policy) h->iter += (uint64_t)iters;  // the policy's Philox counter counts rollout iterations only
   h->pending_deals++;
   return SKYJO_OK;
 }
@@ -162,7 +160,7 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   P.reward_refunded = cfg->reward_refunded, P.illegal_reward = cfg->illegal_reward;
   P.game_id0 = cfg->game_id0;
   h->G = (size_t)P.tiles * SK_TILE;
-  h->lds_bytes = (size_t)P.L.chunks * 1024;
+  h->lds_bytes = (size_t)P.L.chunks * 1024 + 4096;  // tile + 16-word per-lane RNG FIFO / scratch
   const size_t rec16 = (size_t)P.tiles * P.L.chunks * SK_TILE;
   int rc = SKYJO_OK;
   const size_t N = (size_t)cfg->num_players;
@@ -171,7 +169,7 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
       (rc = dalloc(h, &P.mt_idx, 2 * h->G)) || (rc = dalloc(h, &P.seeds, h->G)) ||
       (rc = dalloc(h, &P.deals_consumed, h->G)) || (rc = dalloc(h, &P.rewards, h->G * N)) ||
       (rc = dalloc(h, &P.scores, h->G * N)) || (rc = dalloc(h, &P.done, h->G)) ||
-      (rc = dalloc(h, &P.refill_list, 2 * h->G)) || (rc = dalloc(h, &P.refill_count, 2)) ||
+      (rc = dalloc(h, &P.acc_score, h->G * N)) || (rc = dalloc(h, &P.acc_reward, h->G * N)) ||
       (rc = dalloc(h, &P.counters, 1))) {
     skyjo_vec_destroy(h);
     return rc;
@@ -209,7 +207,6 @@ int skyjo_vec_seed(skyjo_vec *h, const uint64_t *seeds_host, uint64_t base_seed,
     HIPCHK(hipMalloc((void **)&d_seeds, sizeof(uint64_t) * (size_t)h->P.B));
     HIPCHK(hipMemcpyAsync(d_seeds, seeds_host, sizeof(uint64_t) * (size_t)h->P.B, hipMemcpyHostToDevice, s));
   }
-  HIPCHK(hipMemsetAsync(h->P.refill_count, 0, 2 * sizeof(uint32_t), s));
   HIPCHK(hipMemsetAsync(h->P.done, 0, h->G, s));
   hipLaunchKernelGGL(k_seed, dim3((h->P.B + 255) / 256), dim3(256), 0, s, h->P, (const uint64_t *)d_seeds, base_seed, 0,
                      h->P.B);
@@ -235,9 +232,9 @@ int skyjo_vec_reset(skyjo_vec *h, const uint8_t *mask, void *records_out, void *
   if (h->pending_deals > 0 && (rc = launch_deal(h, s, false))) return rc;  // make every next deal available
   dim3 grid(h->P.tiles), block(SK_TILE);
   if (h->P.L.indirect)
-    hipLaunchKernelGGL((k_reset<true>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out, h->list_sel);
+    hipLaunchKernelGGL((k_reset<true>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out);
   else
-    hipLaunchKernelGGL((k_reset<false>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out, h->list_sel);
+    hipLaunchKernelGGL((k_reset<false>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out);
   HIPCHK(hipGetLastError());
   return launch_deal(h, s, false);
 }
@@ -303,14 +300,21 @@ const uint8_t *skyjo_vec_done_ptr(const skyjo_vec *h) { return h ? h->P.done : n
 int skyjo_vec_get_counters(skyjo_vec *h, skyjo_vec_counters *out, void *stream) {
   if (!h || !out) return fail(SKYJO_E_INVALID, "null argument");
   static_assert(sizeof(SkCounters) == sizeof(skyjo_vec_counters), "counter structs must match");
-  HIPCHK(hipMemcpyAsync(out, h->P.counters, sizeof(SkCounters), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(h->P.counters->sum_score, 0, 2 * SKYJO_MAX_PLAYERS * sizeof(double), s));
+  hipLaunchKernelGGL(k_reduce_stats, dim3(64), dim3(256), 0, s, h->P);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, h->P.counters, sizeof(SkCounters), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   return SKYJO_OK;
 }
 
 int skyjo_vec_reset_counters(skyjo_vec *h, void *stream) {
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
+  const size_t n = h->G * (size_t)h->P.L.N * sizeof(double);
   HIPCHK(hipMemsetAsync(h->P.counters, 0, sizeof(SkCounters), (hipStream_t)stream));
+  HIPCHK(hipMemsetAsync(h->P.acc_score, 0, n, (hipStream_t)stream));
+  HIPCHK(hipMemsetAsync(h->P.acc_reward, 0, n, (hipStream_t)stream));
   return SKYJO_OK;
 }
 
@@ -421,11 +425,8 @@ int skyjo_vec_set_state(skyjo_vec *h, int32_t game, const skyjo_game_state *in, 
   return SKYJO_OK;
 }
 
-__global__ void k_invalidate_spare(SkParams P, int g, int list_sel) {
-  if (threadIdx.x == 0 && blockIdx.x == 0 && P.spare_ready[g]) {
-    P.spare_ready[g] = 0;
-    refill_request(P, g, list_sel);
-  }
+__global__ void k_invalidate_spare(SkParams P, int g) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) P.spare_ready[g] = 0;
 }
 
 int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream) {
@@ -436,7 +437,7 @@ int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream)
   int rc;
   if (h->pending_deals > 0 && (rc = launch_deal(h, s, false))) return rc;
   hipLaunchKernelGGL(k_seed_raw, dim3(1), dim3(64), 0, s, h->P, game, value);
-  hipLaunchKernelGGL(k_invalidate_spare, dim3(1), dim3(64), 0, s, h->P, game, h->list_sel);
+  hipLaunchKernelGGL(k_invalidate_spare, dim3(1), dim3(64), 0, s, h->P, game);
   HIPCHK(hipGetLastError());
   return launch_deal(h, s, false);
 }

@@ -38,8 +38,8 @@ struct SkParams {
   double *rewards;          // [tiles*64][N]
   double *scores;           // [tiles*64][N]
   uint8_t *done;            // [tiles*64]
-  int32_t *refill_list;     // [2][tiles*64]
-  uint32_t *refill_count;   // [2]
+  double *acc_score;        // [tiles*64][N] per-game running sums over finished episodes (no atomics)
+  double *acc_reward;       // [tiles*64][N]
   SkCounters *counters;
 };
 
@@ -78,24 +78,81 @@ __device__ __forceinline__ void tile_store(const SkParams &P, uint4 *dst, int ti
 // RNG.  MT mode restates numpy's legacy RandomState (requirements.txt:3 pins numpy==1.21.5; call
 // sites skyjo.py:81,94,101,135): init_genrand, tempering, rk_interval, Fisher-Yates.  The state
 // lives in HBM (2496 B per game, touched only when dealing / reshuffling) and is regenerated
-// lazily: element i of the next block is produced right before it is consumed, which yields the
-// same stream as the classic 624-word block twist.
+// lazily and in place, in stream order, which yields the same stream as the classic 624-word
+// block twist (element i only needs old[i], old[i+1] and element i+397 mod 624).
 // ------------------------------------------------------------------------------------------
+// Regeneration is done 16 elements at a time: all loads of a chunk are issued together, so HBM/L2
+// latency is paid once per 16 draws; the tempered outputs wait in a per-lane LDS ring of DEPTH
+// words (fp[k << 8]).  The persistent state word of a stream is  idx | ahead << 16 : `idx` in
+// [0, 624) is the next position to consume, the `ahead` positions from idx on have already been
+// regenerated in memory (their outputs are re-read from there when the next session opens).
+//   DEPTH 16: the simple form used by the rare in-kernel paths (each lane refills on its own).
+//   DEPTH 64: the dealing kernel; refills happen for the whole wavefront at once (service()), so
+//             the ~450-instruction chunk regeneration never runs for a single lane at a time.
+#define MT_FIFO(k) (*(uint32_t *)(fp + ((k) << 8)))
+__device__ __forceinline__ uint32_t mt_temper(uint32_t v) {
+  v ^= v >> 11;
+  v ^= (v << 7) & 0x9d2c5680u;
+  v ^= (v << 15) & 0xefc60000u;
+  v ^= v >> 18;
+  return v;
+}
+template <int DEPTH>
 struct MtStream {
   uint32_t *mt;
-  int idx;
+  uint8_t *fp;
+  int idx, gen, rp, wp, pend, used;
+  __device__ __forceinline__ static int wrap(int x) { return x >= 624 ? x - 624 : x; }
+  __device__ __forceinline__ void open(uint32_t *mt_, int packed, uint8_t *fp_) {
+    mt = mt_, fp = fp_;
+    idx = packed & 0xffff;
+    idx = idx >= 624 ? 0 : idx;
+    const int ahead = packed >> 16;
+    gen = wrap(idx + ahead), rp = 0, wp = 0, used = 0, pend = 0;
+    if (DEPTH >= 64) {
+      for (int j = 0; j < ahead; j++) MT_FIFO(j) = mt_temper(mt[wrap(idx + j)]);
+      wp = ahead;
+    } else {
+      pend = ahead;
+    }
+  }
+  __device__ __forceinline__ int close() const { return wrap(idx + used) | ((pend + wp - rp) << 16); }
+  __device__ __forceinline__ void refill() {  // regenerate elements gen .. gen+15 in place
+    const int c = gen;
+    uint32_t o[17], x[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) o[k] = mt[c + k];
+    o[16] = mt[c + 16 == 624 ? 0 : c + 16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int i = c + k;
+      x[k] = mt[i < 227 ? i + 397 : i - 227];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      uint32_t y = (o[k] & 0x80000000u) | (o[k + 1] & 0x7fffffffu);
+      uint32_t v = x[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      mt[c + k] = v;
+      MT_FIFO((wp + k) & (DEPTH - 1)) = mt_temper(v);
+    }
+    wp += 16;
+    gen = c + 16 == 624 ? 0 : c + 16;
+  }
+  // called where the active lanes of the wavefront are converged: refill together when all have room
+  __device__ __forceinline__ void service() {
+    if (DEPTH >= 64 && __all(DEPTH - (wp - rp) >= 16)) refill();
+  }
   __device__ __forceinline__ uint32_t next() {
-    if (idx >= 624) idx = 0;
-    const int i = idx;
-    uint32_t a = mt[i], b = mt[i == 623 ? 0 : i + 1], c = mt[i < 227 ? i + 397 : i - 227];
-    uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
-    uint32_t v = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-    mt[i] = v;
-    idx = i + 1;
-    v ^= v >> 11;
-    v ^= (v << 7) & 0x9d2c5680u;
-    v ^= (v << 15) & 0xefc60000u;
-    v ^= v >> 18;
+    uint32_t v;
+    if (DEPTH < 64 && pend > 0) {
+      v = mt_temper(mt[wrap(idx + used)]);
+      pend--;
+    } else {
+      if (rp == wp) refill();
+      v = MT_FIFO(rp & (DEPTH - 1));
+      rp++;
+    }
+    used++;
     return v;
   }
 };
@@ -120,6 +177,7 @@ struct PhiloxStream {
   __device__ __forceinline__ void open(uint64_t key, uint32_t episode, uint32_t resh, uint32_t domain) {
     k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32), blk = 0, c1 = episode, c2 = resh, c3 = domain, pos = 4;
   }
+  __device__ __forceinline__ void service() {}
   __device__ __forceinline__ uint32_t next() {
     if (pos >= 4) {
       philox4x32_10(blk, c1, c2, c3, k0, k1, b0, b1, b2, b3);
@@ -182,23 +240,16 @@ __device__ __forceinline__ void reshuffle_discard(const SkParams &P, uint8_t *lp
   LB(H_RESH) = (uint8_t)(rs < 255 ? rs + 1 : 255);
 }
 
-__device__ __forceinline__ void refill_request(const SkParams &P, int g, int list_sel) {
-  uint32_t slot = atomicAdd(&P.refill_count[list_sel], 1u);
-  P.refill_list[(size_t)list_sel * P.tiles * SK_TILE + slot] = g;
-}
-
-__device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *lp, int g, int list_sel) {
+__device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *lp, uint8_t *fp, int g) {
   if (P.rng_mode == SKYJO_RNG_MT19937) {
     const size_t G = (size_t)P.tiles * SK_TILE;
     const int sel = P.rng_sel[g];
-    MtStream r{P.mt + ((size_t)sel * G + g) * 624, P.mt_idx[(size_t)sel * G + g]};
+    MtStream<16> r;
+    r.open(P.mt + ((size_t)sel * G + g) * 624, P.mt_idx[(size_t)sel * G + g], fp);
     reshuffle_discard(P, lp, r);
-    P.mt_idx[(size_t)sel * G + g] = r.idx;
-    // the pre-dealt next episode was drawn from the stream position before this reshuffle: re-deal it
-    if (P.spare_ready[g]) {
-      P.spare_ready[g] = 0;
-      refill_request(P, g, list_sel);
-    }
+    P.mt_idx[(size_t)sel * G + g] = r.close();
+    // the pre-dealt next episode was drawn from the stream position before this reshuffle: k_deal redoes it
+    P.spare_ready[g] = 0;
   } else {
     PhiloxStream r;
     r.open(P.seeds[g] + 1, *(uint32_t *)(lp + LIDX(H_EPISODE)), LB(H_RESH), 1u);
@@ -210,40 +261,42 @@ __device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *l
 // _evaluate_game + _calc_final_rewards (skyjo.py:477-498, skyjo_env.py:293-312), float64, no FMA
 // contraction (compiled with -ffp-contract=off), numpy's pairwise summation order for the mean.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void finish_game(const SkParams &P, uint8_t *lp, int g, int finisher) {
+__device__ __forceinline__ void finish_game(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int finisher) {
   const int N = P.L.N;
   double *sc = P.scores + (size_t)g * N, *rw = P.rewards + (size_t)g * N;
-  double mn = 0.0;
+  double *as = P.acc_score + (size_t)g * N, *ar = P.acc_reward + (size_t)g * N;
+  // raw integer scores wait in the lane's (idle) RNG FIFO words: MT_FIFO(p), p < 12
+  int mn = 0, fs = 0;
   for (int p = 0; p < N; p++) {
     int s = 0;
     for (int c = 0; c < 4; c++) {
       int b = P.L.off_cards + 12 * p + 3 * c;
       int t0 = LI(b), t1 = LI(b + 1), t2 = LI(b + 2);
-      if (!(t0 == t1 && t1 == t2)) s += t0 + t1 + t2;
+      if (!(t0 == t1 && t1 == t2)) s += t0 + t1 + t2;  // skyjo.py:488-493, hidden cards included
     }
-    double d = (double)s;
-    sc[p] = d;
-    mn = (p == 0 || d < mn) ? d : mn;
+    MT_FIFO(p) = (uint32_t)s;
+    mn = (p == 0 || s < mn) ? s : mn;
+    fs = p == finisher ? s : fs;
   }
-  double fs = sc[finisher];
-  if (mn != fs) sc[finisher] = fs * P.score_penalty;  // skyjo.py:496-497
+  const bool penal = mn != fs;  // skyjo.py:496-497 (integer compare == the float compare of equal-typed sums)
+#define SCORE(p) ((penal && (p) == finisher) ? (double)(int)MT_FIFO(p) * P.score_penalty : (double)(int)MT_FIFO(p))
   double sum;
   if (N < 8) {
     sum = 0.0;
-    for (int p = 0; p < N; p++) sum += sc[p];
+    for (int p = 0; p < N; p++) sum += SCORE(p);
   } else {
-    double r0 = sc[0], r1 = sc[1], r2 = sc[2], r3 = sc[3], r4 = sc[4], r5 = sc[5], r6 = sc[6], r7 = sc[7];
-    sum = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (int p = 8; p < N; p++) sum += sc[p];
+    sum = ((SCORE(0) + SCORE(1)) + (SCORE(2) + SCORE(3))) + ((SCORE(4) + SCORE(5)) + (SCORE(6) + SCORE(7)));
+    for (int p = 8; p < N; p++) sum += SCORE(p);
   }
-  double mean = sum / (double)N;
+  const double mean = sum / (double)N;
   for (int p = 0; p < N; p++) {
-    double r = (-sc[p] + mean) + P.mean_reward;
+    const double d = SCORE(p);
+    double r = (-d + mean) + P.mean_reward;
     if (P.reward_refunded != 0.0) r += (double)LB(P.L.off_refunded + p) * P.reward_refunded;
-    rw[p] = r;
-    atomicAdd(&P.counters->sum_score[p], sc[p]);
-    atomicAdd(&P.counters->sum_reward[p], r);
+    sc[p] = d, rw[p] = r;
+    as[p] += d, ar[p] += r;
   }
+#undef SCORE
   P.done[g] = 1;
 }
 
@@ -253,7 +306,7 @@ __device__ __forceinline__ void finish_game(const SkParams &P, uint8_t *lp, int 
 // Caller guarantees the game is valid and not done.
 // ------------------------------------------------------------------------------------------
 template <bool INDIRECT>
-__device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, int a, int g, int list_sel,
+__device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uint8_t *fp, int a, int g,
                                              LaneCounters &cnt) {
   const int N = P.L.N;
   const int phase = LB(H_PHASE), p = LB(H_PLAYER);
@@ -271,7 +324,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, int
   if (!legal) {  // offender gets illegal_reward, everybody else 0, all done
     double *rw = P.rewards + (size_t)g * N;
     for (int q = 0; q < N; q++) rw[q] = q == p ? P.illegal_reward : 0.0;
-    atomicAdd(&P.counters->sum_reward[p], P.illegal_reward);
+    P.acc_reward[(size_t)g * N + p] += P.illegal_reward;
     LB(H_FLAGS) |= F_DONE;
     LB(H_STATUS) = SKYJO_ST_ILLEGAL;
     P.done[g] = 1;
@@ -287,7 +340,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, int
     if (LB(P.L.off_hidden + p) == 0) {
       LB(H_FLAGS) |= F_TERMINATED | F_DONE;
       LB(H_FINISHER) = (uint8_t)p;
-      finish_game(P, lp, g, p);
+      finish_game(P, lp, fp, g, p);
       cnt.episodes++;
       cnt.sum_len += eplen;
       return;  // nothing drawn, turn not advanced (skyjo.py:350-356)
@@ -296,7 +349,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, int
     if (a == 24) {
       int nd = LB(H_NDRAW);
       if (nd == 0) {
-        reshuffle_dispatch(P, lp, g, list_sel);
+        reshuffle_dispatch(P, lp, fp, g);
         cnt.reshuffles++;
         nd = LB(H_NDRAW);
       }
@@ -470,17 +523,22 @@ __device__ __forceinline__ int policy_pick(const SkParams &P, uint8_t *lp, uint3
 // ------------------------------------------------------------------------------------------
 // Take the pre-dealt next episode (SkyjoGame.reset, skyjo.py:52-74; the dealing itself is k_deal).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, int tile, int lane, int g,
-                                              int list_sel) {
-  if (!P.spare_ready[g]) return false;
+__device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, int tile, int lane, int g) {
+  const uint8_t ready = P.spare_ready[g], sel = P.rng_sel[g];
+  const uint32_t dc = P.deals_consumed[g];
+  if (!ready) return false;
   tile_load(P, P.spare, tile, lane, lp);
-  P.spare_ready[g] = 0;
-  P.rng_sel[g] ^= 1;
-  P.deals_consumed[g]++;
+  P.spare_ready[g] = 0;  // k_deal finds the empty slots with a ballot scan
+  P.rng_sel[g] = sel ^ 1;
+  P.deals_consumed[g] = dc + 1;
   P.done[g] = 0;
-  refill_request(P, g, list_sel);
   return true;
 }
+
+// Fallback when the pre-dealt episode is not available inside a launch (a mid-game reshuffle just
+// invalidated it, or the game already took one in this launch): deal right here, on this lane, from
+// the game's current stream position.  Rare and slow (one lane active), never changes results.
+__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g);
 
 // ------------------------------------------------------------------------------------------
 // k_step: `iters` lockstep iterations over all tiles.  POLICY=false: one iteration with the
@@ -488,11 +546,11 @@ __device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, in
 // ------------------------------------------------------------------------------------------
 template <bool INDIRECT, bool POLICY>
 __global__ __launch_bounds__(SK_TILE) void k_step(SkParams P, const int32_t *actions, uint8_t *rec_out,
-                                                  int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0,
-                                                  int list_sel) {
+                                                  int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0) {
   extern __shared__ uint32_t lds_raw[];
   const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
+  uint8_t *fp = lp + P.L.chunks * 1024;  // 16-word per-lane scratch behind the tile (RNG FIFO)
   tile_load(P, P.state, tile, lane, lp);
   const bool valid = (LB(H_FLAGS) & F_VALID) != 0;
   LaneCounters cnt;
@@ -507,13 +565,12 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams P, const int32_t *act
     if (valid) {
       if (LB(H_FLAGS) & F_DONE) {
         if (P.auto_reset) {
-          if (consume_spare(P, lp, tile, lane, g, list_sel)) {
-            LB(H_STATUS) = SKYJO_ST_RESET;
-            cnt.resets++;
-          } else {
-            LB(H_STATUS) = SKYJO_ST_WAIT;
-            cnt.waits++;
+          if (!consume_spare(P, lp, tile, lane, g)) {
+            deal_inline(P, lp, fp, g);
+            cnt.waits++;  // counts the slow-path deals
           }
+          LB(H_STATUS) = SKYJO_ST_RESET;
+          cnt.resets++;
         } else {
           LB(H_STATUS) = SKYJO_ST_NOOP_DONE;
         }
@@ -524,7 +581,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams P, const int32_t *act
         } else {
           a = actions[g];
         }
-        apply_action<INDIRECT>(P, lp, a, g, list_sel, cnt);
+        apply_action<INDIRECT>(P, lp, fp, a, g, cnt);
       }
       if (rec_out)
         emit_record<INDIRECT>(P, lp, LB(H_PLAYER), rec_out + ((size_t)it * P.B + g) * (size_t)P.L.rec_bytes);
@@ -565,22 +622,21 @@ __global__ __launch_bounds__(SK_TILE) void k_observe(SkParams P, const int32_t *
 
 // SkyjoGame.reset for the masked games: take the pre-dealt episode.
 template <bool INDIRECT>
-__global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *mask, uint8_t *rec_out, int list_sel) {
+__global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *mask, uint8_t *rec_out) {
   extern __shared__ uint32_t lds_raw[];
   const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
+  uint8_t *fp = lp + P.L.chunks * 1024;
   if (g >= P.B) return;
   const bool want = !mask || mask[g];
   bool took = false;
   if (want) {
-    took = consume_spare(P, lp, tile, lane, g, list_sel);
-    if (took) {
-      LB(H_STATUS) = SKYJO_ST_RESET;
-      atomicAdd(&P.counters->resets, 1ull);
-    }
+    took = true;
+    if (!consume_spare(P, lp, tile, lane, g)) deal_inline(P, lp, fp, g);
+    LB(H_STATUS) = SKYJO_ST_RESET;
+    atomicAdd(&P.counters->resets, 1ull);
   }
   if (!took) tile_load(P, P.state, tile, lane, lp);
-  if (want && !took) LB(H_STATUS) = SKYJO_ST_WAIT;
   if (rec_out) emit_record<INDIRECT>(P, lp, LB(H_PLAYER), rec_out + (size_t)g * P.L.rec_bytes);
   if (want) tile_store(P, P.state, tile, lane, lp);
 }
@@ -606,8 +662,8 @@ __global__ void k_seed(SkParams P, const uint64_t *seeds, uint64_t base, int fir
       x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)k;
       mt[k] = x;
     }
-    P.mt_idx[g] = 624;
-    P.mt_idx[G + g] = 624;
+    P.mt_idx[g] = 0;
+    P.mt_idx[G + g] = 0;
   }
 }
 
@@ -623,17 +679,18 @@ __global__ void k_seed_raw(SkParams P, int g, uint32_t value) {
     x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)k;
     mt[k] = x;
   }
-  P.mt_idx[(size_t)sel * G + g] = 624;
+  P.mt_idx[(size_t)sel * G + g] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
 // k_deal: SkyjoGame.reset's dealing (skyjo.py:52-74 with :76-82, :96-103, :105-125, :127-138) for
-// the games in the refill list, one lane per game, written to the game's SPARE record.
+// the games whose spare record is empty, one lane per game, written to the game's SPARE record.
 // RNG order per deal: shuffle(150) -> shuffle(150-12N) -> N x permutation(12)[:2].
 // ------------------------------------------------------------------------------------------
 template <class Rng>
 __device__ __forceinline__ void shuffle_lds(uint8_t *lp, int base, int n, Rng &r) {
   for (int i = n - 1; i >= 1; i--) {
+    r.service();
     int j = (int)rng_interval(r, (uint32_t)i);
     uint8_t t = LB(base + i);
     LB(base + i) = LB(base + j), LB(base + j) = t;
@@ -682,34 +739,66 @@ __device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rn
   refresh_minima(P, lp);
 }
 
-__global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int all) {
+__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g) {
+  const uint32_t ep = P.deals_consumed[g];
+  if (P.rng_mode == SKYJO_RNG_MT19937) {
+    const size_t G = (size_t)P.tiles * SK_TILE;
+    const int sel = P.rng_sel[g];
+    MtStream<16> r;
+    r.open(P.mt + ((size_t)sel * G + g) * 624, P.mt_idx[(size_t)sel * G + g], fp);
+    deal_into_lds(P, lp, r, ep);
+    P.mt_idx[(size_t)sel * G + g] = r.close();
+  } else {
+    PhiloxStream r;
+    r.open(P.seeds[g] + 1, ep, 0u, 0u);
+    deal_into_lds(P, lp, r, ep);
+  }
+  P.deals_consumed[g] = ep + 1;
+  P.done[g] = 0;
+}
+
+// Each workgroup (one wavefront) owns SK_DEAL_SPAN consecutive games, finds the ones whose spare
+// record is empty with a wavefront ballot + prefix popcount, compacts their ids into LDS and then
+// deals them one lane per game, so the long serial shuffles run on densely populated waves.
+#define SK_DEAL_SPAN 256
+__global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int all) {
   extern __shared__ uint32_t lds_raw[];
   const int lane = threadIdx.x;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
+  uint8_t *fp = lp + P.L.chunks * 1024;
+  int32_t *work = (int32_t *)((uint8_t *)lds_raw + P.L.chunks * 1024 + 16384);  // behind the 64-word rings
   const size_t G = (size_t)P.tiles * SK_TILE;
-  const int count = all ? P.B : (int)P.refill_count[list_sel];
-  const int32_t *list = P.refill_list + (size_t)list_sel * G;
-  for (int base = blockIdx.x * SK_TILE; base < count; base += gridDim.x * SK_TILE) {
-    const int i = base + lane;
-    const bool act = i < count;
-    const int g = act ? (all ? i : list[i]) : 0;
+  const int g0 = blockIdx.x * SK_DEAL_SPAN;
+  int count = 0;
+  for (int base = 0; base < SK_DEAL_SPAN; base += SK_TILE) {
+    const int g = g0 + base + lane;
+    const bool need = g < P.B && (all || !P.spare_ready[g]);
+    const unsigned long long b = __ballot(need);
+    if (need) work[count + __popcll(b & ((1ull << lane) - 1ull))] = g;
+    count += __popcll(b);
+  }
+  __syncthreads();
+  for (int base = 0; base < count; base += SK_TILE) {
+    const bool act = base + lane < count;
+    const int g = act ? work[base + lane] : 0;
     if (P.rng_mode == SKYJO_RNG_MT19937) {
       // continue the game's stream in the OTHER buffer, so a mid-game reshuffle of the live episode
       // can still advance the current one and have this deal redone (reshuffle_dispatch)
       const int sel = act ? P.rng_sel[g] : 0;
       const unsigned long long src = (unsigned long long)(P.mt + ((size_t)sel * G + g) * 624);
       const unsigned long long dst = (unsigned long long)(P.mt + ((size_t)(sel ^ 1) * G + g) * 624);
-      for (int l = 0; l < SK_TILE; l++) {  // cooperative, coalesced copy of one 2496-byte state per step
-        if (base + l >= count) break;
-        const uint32_t *s = (const uint32_t *)__shfl(src, l, 64);
-        uint32_t *d = (uint32_t *)__shfl(dst, l, 64);
-        for (int k = lane; k < 624; k += SK_TILE) d[k] = s[k];
+      const int n_act = count - base < SK_TILE ? count - base : SK_TILE;
+      for (int l = 0; l < n_act; l++) {  // cooperative, coalesced copy of one 2496-byte state per step
+        const uint32_t *sp = (const uint32_t *)__shfl(src, l, 64);
+        uint32_t *dp = (uint32_t *)__shfl(dst, l, 64);
+        for (int k = lane; k < 624; k += SK_TILE) dp[k] = sp[k];
       }
       __syncthreads();
       if (act) {
-        MtStream r{(uint32_t *)dst, P.mt_idx[(size_t)sel * G + g]};
+        MtStream<64> r;
+        r.open((uint32_t *)dst, P.mt_idx[(size_t)sel * G + g], fp);
         deal_into_lds(P, lp, r, P.deals_consumed[g]);
-        P.mt_idx[(size_t)(sel ^ 1) * G + g] = r.idx;
+        P.mt_idx[(size_t)(sel ^ 1) * G + g] = r.close();
       }
     } else if (act) {
       PhiloxStream r;
@@ -722,7 +811,21 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
       P.spare_ready[g] = 1;
     }
   }
-  if (!all && blockIdx.x == 0 && lane == 0) P.refill_count[list_sel ^ 1] = 0;
+}
+
+// per-seat sums over all games for skyjo_vec_get_counters (the hot path keeps per-game sums, no atomics)
+__global__ void k_reduce_stats(SkParams P) {
+  const int N = P.L.N;
+  for (int p = 0; p < N; p++) {
+    double a = 0.0, b = 0.0;
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < P.B; g += gridDim.x * blockDim.x)
+      a += P.acc_score[(size_t)g * N + p], b += P.acc_reward[(size_t)g * N + p];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64), b += __shfl_down(b, off, 64);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&P.counters->sum_score[p], a);
+      atomicAdd(&P.counters->sum_reward[p], b);
+    }
+  }
 }
 
 // records -> the reference's dense arrays (obs int8[n][D], mask int8[n][26], ...)

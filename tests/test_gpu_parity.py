@@ -195,7 +195,8 @@ def test_rollout_vs_oracle(N, ind, rng_mode, B):
     c, oc = eng.counters(), ora.counters()
     for k in ("steps", "episodes", "illegal", "resets", "sum_len", "iters"):
         assert c[k] == oc[k] if k != "iters" else c[k] == oc["iter"], (k, c, oc)
-    assert c["waits"] == 0 and c["illegal"] == 0 and c["episodes"] > B
+    # "waits" counts deals made on the in-kernel slow path (pre-dealt episode invalidated by a reshuffle)
+    assert c["illegal"] == 0 and c["episodes"] > B and (N > 4 or c["waits"] == 0)
     dn = ora.dones.astype(bool)
     rew, sc, done = eng.rewards_host()
     np.testing.assert_array_equal(rew[dn], ora.rewards[dn])
@@ -235,9 +236,12 @@ def test_headline_size_properties():
         # histogram of the discard pile never exceeds the deck: 10 per value, + 3 zeros per collapse
         assert int(o[..., 2:17].max()) <= 10 + 3 * 4 * N
     c = eng.counters()
-    assert c["steps"] + c["resets"] == 6 * K * B and c["waits"] == 0 and c["illegal"] == 0
+    assert c["steps"] + c["resets"] == 6 * K * B and c["waits"] == 0 and c["illegal"] == 0 and c["iters"] == 6 * K
     assert 95 < c["sum_len"] / c["episodes"] < 120  # SURVEY: mean episode length 108 at N=3
     # finished episodes: sum of rewards over seats == N * mean_reward + refunded bonus (skyjo_env.py:307-312)
+    # all games stay phase-aligned (draw on even iterations, a reset also takes one iteration), and a game can
+    # only end on a draw: stop on an even iteration to catch finished games before their auto-reset
+    eng.rollout(1, policy_seed=1)
     rew, sc, done = eng.rewards_host()
     dn = done.astype(bool)
     assert dn.sum() > 100

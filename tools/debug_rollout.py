@@ -1,0 +1,25 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from skyjo_rl_amd import SkyjoVecEnv
+from oracle import skyjo_oracle as so
+N, B, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+rng_mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+cfg = dict(num_players=N, score_penalty=2.0, observe_other_player_indirect=True, mean_reward=1.0,
+           reward_refunded=0.001, rng_mode=rng_mode, auto_reset=True)
+eng = SkyjoVecEnv(B, game_id0=1000, **cfg)
+ora = so.OracleVec(num_envs=B, game_id0=1000, **cfg)
+eng.seed(None, 99); ora.seed(None, 99)
+for r in range(40):
+    rec = eng.new_records(K)
+    act = torch.empty((K, B), dtype=torch.int32, device="cuda")
+    eng.rollout(K, policy_seed=4242, records=rec, actions=act)
+    torch.cuda.synchronize()
+    oact = ora.rollout(K, 4242, record_actions=True)
+    a = act.cpu().numpy()
+    c = eng.counters()
+    print(r, "mismatch", int((a != oact).sum()), "slow deals", c["waits"], "resh", c["reshuffles"], "eps", c["episodes"], flush=True)
+    if (a != oact).any():
+        t, g = np.argwhere(a != oact)[0]
+        print("first mismatch iter", t, "game", g, a[t, g], oact[t, g])
+        break
