@@ -1,0 +1,56 @@
+"""Multi-GPU sharding: games are independent, so a batch shards by global game id with no
+data-path collective; the only exchange is an all-gather of per-rank episode statistics
+(RCCL when the tensors live on the GPU: torch.distributed backend "nccl" is RCCL on ROCm).
+
+One process per GPU.  Game g is seeded ``base_seed + g`` and its policy stream is keyed by g, so
+trajectories do not depend on how many ranks the batch is split over.
+"""
+import numpy as np
+
+STAT_FIELDS = ("steps", "episodes", "illegal", "resets", "sum_len", "reshuffles", "waits")
+
+
+def shard_range(total_envs, world_size, rank):
+    """Contiguous block of games owned by `rank`: (first global game id, number of games)."""
+    base, rem = divmod(int(total_envs), int(world_size))
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+def make_sharded_env(total_envs, rank, world_size, engine_factory=None, **config):
+    """Local engine for this rank's shard of a `total_envs`-game batch."""
+    first, count = shard_range(total_envs, world_size, rank)
+    if engine_factory is None:
+        from .vec_env import SkyjoVecEnv as engine_factory
+    return engine_factory(count, game_id0=first, **config)
+
+
+def stats_record(counters, num_players):
+    """Fixed-size float64 record [len(STAT_FIELDS) + 2 * num_players] of one rank."""
+    rec = [float(counters.get(k, 0)) for k in STAT_FIELDS]
+    for key in ("sum_score", "sum_reward"):
+        v = counters.get(key)
+        rec += [float(x) for x in (v if v is not None else np.zeros(num_players))][:num_players]
+    return rec
+
+
+def gather_stats(counters, num_players, device=None):
+    """All-gather the per-rank statistics record; returns (per_rank [W, F] ndarray, totals dict)."""
+    import torch
+    import torch.distributed as dist
+
+    rec = torch.tensor(stats_record(counters, num_players), dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        out = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, rec)
+        allr = torch.stack(out).cpu().numpy()
+    else:
+        allr = rec.cpu().numpy()[None]
+    tot = allr.sum(0)
+    totals = {k: tot[i] for i, k in enumerate(STAT_FIELDS)}
+    n = len(STAT_FIELDS)
+    totals["sum_score"] = tot[n:n + num_players]
+    totals["sum_reward"] = tot[n + num_players:n + 2 * num_players]
+    totals["mean_episode_len"] = totals["sum_len"] / max(totals["episodes"], 1.0)
+    return allr, totals
