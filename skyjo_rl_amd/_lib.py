@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libskyjo_vec.so")
+LIB_PATH = os.environ.get("SKYJO_LIB") or os.path.join(_HERE, "libskyjo_vec.so")  # SKYJO_LIB: diagnostic builds
 
 ABI_VERSION = 1
 MAX_PLAYERS = 12
@@ -73,6 +73,7 @@ SIGNATURES = {
     "skyjo_vec_seed_raw": (C.c_int, [VP, I32, U32, VP]),
     "skyjo_vec_profile": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(I64), C.POINTER(C.c_double),
                                     C.POINTER(I64)]),
+    "skyjo_vec_debug_stamps": (C.c_int, [VP, VP]),
     "skyjo_vec_set_option": (C.c_int, [VP, C.c_int, I64]),
     "skyjo_vec_step_host": (C.c_int, [VP, VP, VP]),
     "skyjo_vec_observe_host": (C.c_int, [VP, VP, VP]),

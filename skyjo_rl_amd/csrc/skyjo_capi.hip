@@ -36,11 +36,12 @@ struct skyjo_vec {
   skyjo_vec_config cfg{};
   SkParams P{};
   size_t G = 0;           // tiles * 64
-  size_t lds_bytes = 0;
+  size_t lds_bytes = 0, lds_tile = 0;
   bool seeded = false;
   int pending_deals = 0;  // step launches since the dealing kernel last ran
   int deal_interval = 1;
-  uint64_t iter = 0;
+  uint64_t iter = 0;        // rollout iterations (the policy's Philox counter)
+  uint64_t iters_total = 0; // lockstep iterations of any kind since the counters were reset
   // lazily allocated scratch for the *_host conveniences
   int32_t *d_actions = nullptr;
   uint8_t *d_records = nullptr;
@@ -83,7 +84,7 @@ int launch_deal(skyjo_vec *h, hipStream_t s, bool all) {
   const int blocks = (h->P.B + SK_DEAL_SPAN - 1) / SK_DEAL_SPAN;
   int rc;
   if ((rc = prof_begin(h, h->ev_deal, s))) return rc;
-  hipLaunchKernelGGL(k_deal, dim3(blocks), dim3(SK_TILE), h->lds_bytes - 4096 + 16384 + SK_DEAL_SPAN * sizeof(int32_t), s, h->P,
+  hipLaunchKernelGGL(k_deal, dim3(blocks), dim3(SK_TILE), h->lds_tile + 16384 + SK_DEAL_SPAN * sizeof(int32_t), s, h->P,
                      all ? 1 : 0);
   HIPCHK(hipGetLastError());
   if ((rc = prof_end(h, h->ev_deal, s))) return rc;
@@ -107,6 +108,7 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
 #undef LAUNCH
   HIPCHK(hipGetLastError());
   if ((prc = prof_end(h, h->ev_step, s))) return prc;
+  h->iters_total += (uint64_t)iters;
   if (policy) h->iter += (uint64_t)iters;  // the policy's Philox counter counts rollout iterations only
   h->pending_deals++;
   return SKYJO_OK;
@@ -160,7 +162,8 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   P.reward_refunded = cfg->reward_refunded, P.illegal_reward = cfg->illegal_reward;
   P.game_id0 = cfg->game_id0;
   h->G = (size_t)P.tiles * SK_TILE;
-  h->lds_bytes = (size_t)P.L.chunks * 1024 + 4096;  // tile + 16-word per-lane RNG FIFO / scratch
+  h->lds_tile = (size_t)P.L.chunks * 1024;
+  h->lds_bytes = h->lds_tile + 4096 + 2 * (size_t)cfg->num_players * 512;  // tile + 16-word RNG scratch + float64 sums
   const size_t rec16 = (size_t)P.tiles * P.L.chunks * SK_TILE;
   int rc = SKYJO_OK;
   const size_t N = (size_t)cfg->num_players;
@@ -169,8 +172,8 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
       (rc = dalloc(h, &P.mt_idx, 2 * h->G)) || (rc = dalloc(h, &P.seeds, h->G)) ||
       (rc = dalloc(h, &P.deals_consumed, h->G)) || (rc = dalloc(h, &P.rewards, h->G * N)) ||
       (rc = dalloc(h, &P.scores, h->G * N)) || (rc = dalloc(h, &P.done, h->G)) ||
-      (rc = dalloc(h, &P.acc_score, h->G * N)) || (rc = dalloc(h, &P.acc_reward, h->G * N)) ||
-      (rc = dalloc(h, &P.counters, 1))) {
+      (rc = dalloc(h, &P.acc_tile, (size_t)P.tiles * 2 * SKYJO_MAX_PLAYERS)) ||
+      (rc = dalloc(h, &P.counters, 1)) || (rc = dalloc(h, &P.tile_counters, (size_t)P.tiles * 8)) || (rc = dalloc(h, &P.stamps, (size_t)P.tiles * 8))) {
     skyjo_vec_destroy(h);
     return rc;
   }
@@ -301,20 +304,22 @@ int skyjo_vec_get_counters(skyjo_vec *h, skyjo_vec_counters *out, void *stream) 
   if (!h || !out) return fail(SKYJO_E_INVALID, "null argument");
   static_assert(sizeof(SkCounters) == sizeof(skyjo_vec_counters), "counter structs must match");
   hipStream_t s = (hipStream_t)stream;
-  HIPCHK(hipMemsetAsync(h->P.counters->sum_score, 0, 2 * SKYJO_MAX_PLAYERS * sizeof(double), s));
+  HIPCHK(hipMemsetAsync(h->P.counters, 0, sizeof(SkCounters), s));
   hipLaunchKernelGGL(k_reduce_stats, dim3(64), dim3(256), 0, s, h->P);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, h->P.counters, sizeof(SkCounters), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize(s));
+  out->iters = h->iters_total;
   return SKYJO_OK;
 }
 
 int skyjo_vec_reset_counters(skyjo_vec *h, void *stream) {
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
-  const size_t n = h->G * (size_t)h->P.L.N * sizeof(double);
+  const size_t n = (size_t)h->P.tiles * 2 * SKYJO_MAX_PLAYERS * sizeof(double);
+  h->iters_total = 0;
   HIPCHK(hipMemsetAsync(h->P.counters, 0, sizeof(SkCounters), (hipStream_t)stream));
-  HIPCHK(hipMemsetAsync(h->P.acc_score, 0, n, (hipStream_t)stream));
-  HIPCHK(hipMemsetAsync(h->P.acc_reward, 0, n, (hipStream_t)stream));
+  HIPCHK(hipMemsetAsync(h->P.tile_counters, 0, (size_t)h->P.tiles * 8 * sizeof(unsigned long long), (hipStream_t)stream));
+  HIPCHK(hipMemsetAsync(h->P.acc_tile, 0, n, (hipStream_t)stream));
   return SKYJO_OK;
 }
 
@@ -463,6 +468,16 @@ int skyjo_vec_profile(skyjo_vec *h, int enable, double *step_ms, int64_t *step_l
   if (deal_ms) *deal_ms = tot[1];
   if (deal_launches) *deal_launches = cnt[1];
   h->profile = enable != 0;
+  return SKYJO_OK;
+}
+
+int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out8_host) {
+  if (!h || !out8_host) return fail(SKYJO_E_INVALID, "null argument");
+  std::vector<unsigned long long> t((size_t)h->P.tiles * 8);
+  HIPCHK(hipMemcpy(t.data(), h->P.stamps, t.size() * 8, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 8; k++) out8_host[k] = 0;
+  for (size_t i = 0; i < t.size(); i++) out8_host[i & 7] += t[i];
+  HIPCHK(hipMemset(h->P.stamps, 0, t.size() * 8));
   return SKYJO_OK;
 }
 

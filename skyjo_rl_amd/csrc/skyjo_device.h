@@ -38,9 +38,10 @@ struct SkParams {
   double *rewards;          // [tiles*64][N]
   double *scores;           // [tiles*64][N]
   uint8_t *done;            // [tiles*64]
-  double *acc_score;        // [tiles*64][N] per-game running sums over finished episodes (no atomics)
-  double *acc_reward;       // [tiles*64][N]
+  double *acc_tile;         // [tiles][2][12] per-wavefront sums of final scores / rewards per seat
   SkCounters *counters;
+  unsigned long long *tile_counters;  // [tiles][8] per-wavefront event counts (no same-address atomics)
+  unsigned long long *stamps;         // [tiles][8] section cycle sums, written only by -DSK_STAMPS diagnostic builds
 };
 
 struct LaneCounters {
@@ -57,20 +58,40 @@ struct LaneCounters {
 #define LH(b) (*(uint16_t *)(lp + LIDX(b)))
 #define LSH(b) (*(int16_t *)(lp + LIDX(b)))
 
+// Groups of 6 chunks: all global loads of a group are issued before the first LDS write, so a tile
+// costs ceil(chunks / 6) memory round trips instead of one per chunk (the trip count is a run-time
+// value, the compiler does not pipeline this loop by itself).
 __device__ __forceinline__ void tile_load(const SkParams &P, const uint4 *src, int tile, int lane, uint8_t *lp) {
   const uint4 *s = src + (size_t)tile * P.L.chunks * SK_TILE + lane;
-  for (int c = 0; c < P.L.chunks; c++) {
-    uint4 v = s[(size_t)c * SK_TILE];
-    LW(4 * c + 0) = v.x, LW(4 * c + 1) = v.y, LW(4 * c + 2) = v.z, LW(4 * c + 3) = v.w;
+  const int n = P.L.chunks;
+  for (int c = 0; c < n; c += 6) {
+    uint4 v[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (c + k < n) v[k] = s[(size_t)(c + k) * SK_TILE];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (c + k < n) {
+        const int w = 4 * (c + k);
+        LW(w + 0) = v[k].x, LW(w + 1) = v[k].y, LW(w + 2) = v[k].z, LW(w + 3) = v[k].w;
+      }
   }
 }
 
 __device__ __forceinline__ void tile_store(const SkParams &P, uint4 *dst, int tile, int lane, uint8_t *lp) {
   uint4 *d = dst + (size_t)tile * P.L.chunks * SK_TILE + lane;
-  for (int c = 0; c < P.L.chunks; c++) {
-    uint4 v;
-    v.x = LW(4 * c + 0), v.y = LW(4 * c + 1), v.z = LW(4 * c + 2), v.w = LW(4 * c + 3);
-    d[(size_t)c * SK_TILE] = v;
+  const int n = P.L.chunks;
+  for (int c = 0; c < n; c += 6) {
+    uint4 v[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (c + k < n) {
+        const int w = 4 * (c + k);
+        v[k].x = LW(w + 0), v[k].y = LW(w + 1), v[k].z = LW(w + 2), v[k].w = LW(w + 3);
+      }
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (c + k < n) d[(size_t)(c + k) * SK_TILE] = v[k];
   }
 }
 
@@ -261,10 +282,16 @@ __device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *l
 // _evaluate_game + _calc_final_rewards (skyjo.py:477-498, skyjo_env.py:293-312), float64, no FMA
 // contraction (compiled with -ffp-contract=off), numpy's pairwise summation order for the mean.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void finish_game(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int finisher) {
+// per-lane float64 accumulators behind the RNG scratch: element k of lane l at ap + k * 512 (ap = base + l * 8)
+#define ACC(k) (*(double *)(ap + ((k) << 9)))
+__device__ __forceinline__ void acc_add(uint8_t *ap, int k, double v) {
+  __hip_atomic_fetch_add(&ACC(k), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+__device__ __forceinline__ void finish_game(const SkParams &P, uint8_t *lp, uint8_t *fp, uint8_t *ap, int g,
+                                            int finisher) {
   const int N = P.L.N;
   double *sc = P.scores + (size_t)g * N, *rw = P.rewards + (size_t)g * N;
-  double *as = P.acc_score + (size_t)g * N, *ar = P.acc_reward + (size_t)g * N;
   // raw integer scores wait in the lane's (idle) RNG FIFO words: MT_FIFO(p), p < 12
   int mn = 0, fs = 0;
   for (int p = 0; p < N; p++) {
@@ -294,29 +321,123 @@ __device__ __forceinline__ void finish_game(const SkParams &P, uint8_t *lp, uint
     double r = (-d + mean) + P.mean_reward;
     if (P.reward_refunded != 0.0) r += (double)LB(P.L.off_refunded + p) * P.reward_refunded;
     sc[p] = d, rw[p] = r;
-    as[p] += d, ar[p] += r;
+    acc_add(ap, p, d), acc_add(ap, N + p, r);
   }
 #undef SCORE
   P.done[g] = 1;
 }
 
 // ------------------------------------------------------------------------------------------
+// Hot path.  The three header words live in registers (HdrRegs) for a whole launch; one turn costs
+// three dependent LDS round trips: (A) the acting player's card / vis rows, (B) the pile byte that
+// is drawn, (C) the histogram words and the next player's vis row for the output record.
+// Histogram bins are bumped with fire-and-forget dword LDS atomics (bin k is byte k & 3 of its
+// word; counts stay far below 256 so no carry crosses a byte).
+// ------------------------------------------------------------------------------------------
+// Diagnostic builds (-DSK_STAMPS) sum s_memtime deltas per section into P.stamps; the shipped build has none.
+struct Stamps {
+  unsigned long long t, acc[8];
+};
+#ifdef SK_STAMPS
+#define STAMP_DECL Stamps st; st.t = __builtin_amdgcn_s_memtime(); for (int k_ = 0; k_ < 8; k_++) st.acc[k_] = 0
+#define STAMP(i)                                                 \
+  do {                                                           \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    __builtin_amdgcn_s_waitcnt(0);                               \
+    unsigned long long st_n = __builtin_amdgcn_s_memtime();      \
+    __builtin_amdgcn_s_waitcnt(0);                               \
+    st.acc[i] += st_n - st.t;                                    \
+    st.t = st_n;                                                 \
+    __builtin_amdgcn_sched_barrier(0);                           \
+  } while (0)
+#define STAMP_STORE                                                        \
+  do {                                                                     \
+    if (lane == 0)                                                         \
+      for (int k = 0; k < 8; k++) P.stamps[(size_t)tile * 8 + k] += st.acc[k]; \
+  } while (0)
+#else
+#define STAMP_DECL Stamps st
+#define STAMP(i)
+#define STAMP_STORE
+#endif
+
+struct HdrRegs {
+  uint32_t w0, w1, w2;  // bytes 0..3, 4..7, 8..11 of the record (skyjo_layout.h)
+};
+#define HDR_LOAD(h) ((h).w0 = LW(0), (h).w1 = LW(1), (h).w2 = LW(2))
+#define HDR_FLUSH(h) (LW(0) = (h).w0, LW(1) = (h).w1, LW(2) = (h).w2)
+
+__device__ __forceinline__ int byte3(uint32_t a, uint32_t b, uint32_t c, int k) {  // signed byte k of a 12-byte row
+  const uint32_t w = k < 4 ? a : (k < 8 ? b : c);
+  return (int)(int8_t)(w >> ((k & 3) * 8));
+}
+__device__ __forceinline__ void put3(uint32_t &a, uint32_t &b, uint32_t &c, int k, int val) {
+  const uint32_t sh = (uint32_t)(k & 3) * 8u, m = ~(0xffu << sh), v = ((uint32_t)val & 0xffu) << sh;
+  if (k < 4) a = (a & m) | v;
+  else if (k < 8) b = (b & m) | v;
+  else c = (c & m) | v;
+}
+__device__ __forceinline__ void hist_add(uint8_t *lp, int value, int delta) {  // bins live at bytes 18..32
+  const int b = H_HIST + 2 + value;
+  uint32_t *w = (uint32_t *)(lp + ((b >> 2) << 8));
+  const uint32_t d = (uint32_t)delta << ((b & 3) * 8);
+  __hip_atomic_fetch_add(w, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ uint32_t swar_nonzero01(uint32_t x) {
+  return ((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u) >> 7;
+}
+__device__ __forceinline__ uint32_t pack12(uint32_t a, uint32_t b, uint32_t c) {  // 0/1 bytes -> 12 bits
+  return ((a * 0x00204081u >> 21) & 0xfu) | (((b * 0x00204081u >> 21) & 0xfu) << 4) |
+         (((c * 0x00204081u >> 21) & 0xfu) << 8);
+}
+
+// uniform choice over the legal actions == policy_ra's p = mask / sum(mask)
+// (rlskyjo/models/random_admissible_policy.py:26-28); word = Philox4x32-10 output for this
+// (game, iteration), k = mulhi(word, n_legal), action = k-th legal action in ascending order.
+__device__ __forceinline__ int policy_pick(int phase, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t word) {
+  if (phase == 0) return 24 + (int)__umulhi(word, 2u);
+  uint32_t legal = pack12(swar_nonzero01(q0 ^ 0xf2f2f2f2u), swar_nonzero01(q1 ^ 0xf2f2f2f2u),
+                          swar_nonzero01(q2 ^ 0xf2f2f2f2u)) |
+                   (pack12(swar_nonzero01(q0 ^ 0x0f0f0f0fu) ^ 0x01010101u, swar_nonzero01(q1 ^ 0x0f0f0f0fu) ^ 0x01010101u,
+                           swar_nonzero01(q2 ^ 0x0f0f0f0fu) ^ 0x01010101u)
+                    << 12);
+  const int n = __popc(legal);
+  if (n == 0) return 24;
+  int k = (int)__umulhi(word, (uint32_t)n), pos = 0;
+  // position of the k-th set bit of a 24-bit mask: halving search on popcounts, no loop
+  int c = __popc(legal & 0xfffu);
+  if (k >= c) k -= c, pos = 12, legal >>= 12;
+  c = __popc(legal & 0x3fu);
+  if (k >= c) k -= c, pos += 6, legal >>= 6;
+  c = __popc(legal & 0x7u);
+  if (k >= c) k -= c, pos += 3, legal >>= 3;
+  c = (int)(legal & 1u);
+  if (k >= c) {
+    k -= c, pos += 1;
+    c = (int)((legal >> 1) & 1u);
+    if (k >= c) pos += 1;
+  }
+  return pos;
+}
+
+// ------------------------------------------------------------------------------------------
 // SkyjoGame.act (skyjo.py:308-335) for the expected player, preceded by the legality test of
 // TerminateIllegalWrapper (skyjo_env.py:23) on the action mask of skyjo.py:201-224.
+// v0..v2: the acting player's vis row (already loaded by the caller for the policy).
 // Caller guarantees the game is valid and not done.
 // ------------------------------------------------------------------------------------------
 template <bool INDIRECT>
-__device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uint8_t *fp, int a, int g,
-                                             LaneCounters &cnt) {
+__device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uint8_t *fp, uint8_t *ap, HdrRegs &h, uint32_t v0,
+                                             uint32_t v1, uint32_t v2, int a, int g, LaneCounters &cnt, Stamps &st) {
   const int N = P.L.N;
-  const int phase = LB(H_PHASE), p = LB(H_PLAYER);
-  const int visb = P.L.off_vis + 12 * p, cardb = P.L.off_cards + 12 * p, pb = P.L.off_pile;
+  const int phase = h.w0 & 0xff, p = (h.w0 >> 8) & 0xff;
+  const int cardb = P.L.off_cards + 12 * p, visb = cardb + 12 * N, pb = P.L.off_pile;
   const unsigned ua = (unsigned)a;
   int slot = 0, sv = 0;
   bool legal;
   if (ua < 24u) {
     slot = a < 12 ? a : a - 12;
-    sv = LI(visb + slot);
+    sv = byte3(v0, v1, v2, slot);
     legal = phase == 1 && (a < 12 ? sv != SKYJO_REFUNDED : sv == SKYJO_HAND_NONE);
   } else {
     legal = ua <= 25u && phase == 0;
@@ -324,98 +445,111 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
   if (!legal) {  // offender gets illegal_reward, everybody else 0, all done
     double *rw = P.rewards + (size_t)g * N;
     for (int q = 0; q < N; q++) rw[q] = q == p ? P.illegal_reward : 0.0;
-    P.acc_reward[(size_t)g * N + p] += P.illegal_reward;
-    LB(H_FLAGS) |= F_DONE;
-    LB(H_STATUS) = SKYJO_ST_ILLEGAL;
+    acc_add(ap, N + p, P.illegal_reward);
+    h.w0 = (h.w0 & 0x0000ffffu) | ((((h.w0 >> 16) & 0xffu) | F_DONE) << 16) | ((uint32_t)SKYJO_ST_ILLEGAL << 24);
     P.done[g] = 1;
     cnt.illegal++;
     return;
   }
-  LB(H_STATUS) = SKYJO_ST_OK;
-  const int eplen = LH(H_EPLEN) + 1;
-  LH(H_EPLEN) = (uint16_t)eplen;
+  const int eplen = (int)(h.w2 & 0xffffu) + 1;
+  h.w2 = (h.w2 & 0xffff0000u) | (uint32_t)eplen;
+  h.w0 &= 0x00ffffffu;  // status OK
   cnt.steps++;
   if (phase == 0) {
     // _action_draw_card (skyjo.py:337-374): goal check first, on the drawing player
     if (LB(P.L.off_hidden + p) == 0) {
-      LB(H_FLAGS) |= F_TERMINATED | F_DONE;
+      h.w0 |= (uint32_t)(F_TERMINATED | F_DONE) << 16;
       LB(H_FINISHER) = (uint8_t)p;
-      finish_game(P, lp, fp, g, p);
+      finish_game(P, lp, fp, ap, g, p);
       cnt.episodes++;
       cnt.sum_len += eplen;
       return;  // nothing drawn, turn not advanced (skyjo.py:350-356)
     }
     int hand;
     if (a == 24) {
-      int nd = LB(H_NDRAW);
-      if (nd == 0) {
+      int nd = h.w1 & 0xff;
+      if (nd == 0) {  // rare: works on the LDS copy of the header
+        HDR_FLUSH(h);
+#ifndef SK_EXPERIMENT_NO_RARE
         reshuffle_dispatch(P, lp, fp, g);
+#endif
+        HDR_LOAD(h);
         cnt.reshuffles++;
-        nd = LB(H_NDRAW);
+        nd = h.w1 & 0xff;
       }
       nd--;
-      hand = LI(pb + pile_addr(LB(H_ROLE), nd));
-      LB(H_NDRAW) = (uint8_t)nd;
+      hand = LI(pb + pile_addr((h.w1 >> 16) & 1, nd));
+      h.w1 = (h.w1 & 0xffffff00u) | (uint32_t)nd;
     } else {
-      const int reg = LB(H_ROLE) ^ 1;
-      int ns = LB(H_NDISC) - 1;
+      const int reg = ((h.w1 >> 16) & 1) ^ 1;
+      const int ns = (int)((h.w1 >> 8) & 0xff) - 1;
       hand = LI(pb + pile_addr(reg, ns));
-      LB(H_HIST + 2 + hand)--;
-      LB(H_NDISC) = (uint8_t)ns;
-      LB(H_TOP) = ns > 0 ? LB(pb + pile_addr(reg, ns - 1)) : (uint8_t)(int8_t)-3;  // skyjo.py:254
+      const int below = LI(pb + pile_addr(reg, ns > 0 ? ns - 1 : 0));
+      hist_add(lp, hand, -1);
+      const int top = ns > 0 ? below : -3;  // skyjo.py:254
+      h.w1 = (h.w1 & 0x00ff00ffu) | ((uint32_t)ns << 8) | (((uint32_t)top & 0xffu) << 24);
     }
-    LB(H_HAND) = (uint8_t)hand;
-    LB(H_PHASE) = 1;
+    h.w2 = (h.w2 & 0x00ffffffu) | (((uint32_t)hand & 0xffu) << 24);
+    h.w0 = (h.w0 & 0xffffff00u) | 1u;  // phase = place
     return;
   }
+  STAMP(4);
   // _action_place (skyjo.py:376-427)
-  const int hand = LI(H_HAND);
-  const int reg = LB(H_ROLE) ^ 1;
-  int ns = LB(H_NDISC);
-  int sum = LSH(P.L.off_sums + 2 * p);
+  const int hand = (int)(int8_t)(h.w2 >> 24);
+  const int reg = ((h.w1 >> 16) & 1) ^ 1;
+  int ns = (h.w1 >> 8) & 0xff;
+  const int cw = cardb >> 2;
+  const uint32_t c0 = LW(cw), c1 = LW(cw + 1), c2 = LW(cw + 2);
+  int sum = LSH(P.L.off_sums + 2 * p), hid = LB(P.L.off_hidden + p);
+  // minima over the OTHER players do not change in this turn (skyjo.py:182-183)
+  int oms = 1 << 20, omh = 1 << 20;
+  for (int q = 0; q < N; q++) {
+    const int s = LSH(P.L.off_sums + 2 * q), hq = LB(P.L.off_hidden + q);
+    oms = (q != p && s < oms) ? s : oms, omh = (q != p && hq < omh) ? hq : omh;
+  }
   int top;
   if (a < 12) {  // swap hand card with slot a; the old card (open or hidden) goes to the discard pile
-    const int old = LI(cardb + a);
+    const int old = byte3(c0, c1, c2, a);
     LB(pb + pile_addr(reg, ns)) = (uint8_t)old;
     ns++;
-    LB(H_HIST + 2 + old)++;
+    hist_add(lp, old, 1);
     LB(cardb + a) = (uint8_t)hand;
     LB(visb + a) = (uint8_t)hand;
+    put3(v0, v1, v2, a, hand);
     if (sv == SKYJO_HAND_NONE) {
       sum += hand;
-      LB(P.L.off_hidden + p)--;
+      hid--;
     } else {
       sum += hand - old;
-      if (!INDIRECT) LB(H_HIST + 2 + old)--;  // an open card leaves the table (skyjo.py:240-244)
+      if (!INDIRECT) hist_add(lp, old, -1);  // an open card leaves the table (skyjo.py:240-244)
     }
-    if (!INDIRECT) LB(H_HIST + 2 + hand)++;
+    if (!INDIRECT) hist_add(lp, hand, 1);
     top = old;
   } else {  // discard the hand card and reveal slot
-    const int c = LI(cardb + slot);
+    const int c = byte3(c0, c1, c2, slot);
     LB(pb + pile_addr(reg, ns)) = (uint8_t)hand;
     ns++;
-    LB(H_HIST + 2 + hand)++;
+    hist_add(lp, hand, 1);
     LB(visb + slot) = (uint8_t)c;
-    LB(P.L.off_hidden + p)--;
+    put3(v0, v1, v2, slot, c);
+    hid--;
     sum += c;
-    if (!INDIRECT) LB(H_HIST + 2 + c)++;
+    if (!INDIRECT) hist_add(lp, c, 1);
     top = hand;
   }
   // _remask_refunded_player_cards_jit (skyjo.py:431-469): all 4 columns of the acting player
   {
-    const int vw = visb >> 2;
-    uint32_t w0 = LW(vw), w1 = LW(vw + 1), w2 = LW(vw + 2);
     bool any = false;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       uint32_t tri;  // the three bytes 3c, 3c+1, 3c+2
-      if (c == 0) tri = w0 & 0xffffffu;
-      else if (c == 1) tri = (w0 >> 24) | ((w1 & 0xffffu) << 8);
-      else if (c == 2) tri = (w1 >> 16) | ((w2 & 0xffu) << 16);
-      else tri = w2 >> 8;
-      int v0 = (int)(int8_t)(tri & 0xff);
-      bool same = ((tri >> 8) & 0xff) == (tri & 0xff) && ((tri >> 16) & 0xff) == (tri & 0xff);
-      if (same && v0 != SKYJO_HAND_NONE && v0 != SKYJO_REFUNDED) {
+      if (c == 0) tri = v0 & 0xffffffu;
+      else if (c == 1) tri = (v0 >> 24) | ((v1 & 0xffffu) << 8);
+      else if (c == 2) tri = (v1 >> 16) | ((v2 & 0xffu) << 16);
+      else tri = v2 >> 8;
+      const int t0 = (int)(int8_t)(tri & 0xff);
+      const bool same = ((tri >> 8) & 0xff) == (tri & 0xff) && ((tri >> 16) & 0xff) == (tri & 0xff);
+      if (same && t0 != SKYJO_HAND_NONE && t0 != SKYJO_REFUNDED) {
         for (int k = 0; k < 3; k++) {
           LB(cardb + 3 * c + k) = (uint8_t)(int8_t)SKYJO_REFUNDED;
           LB(visb + 3 * c + k) = (uint8_t)(int8_t)SKYJO_REFUNDED;
@@ -423,9 +557,9 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
           LB(pb + pile_addr(reg, ns)) = 0;
           ns++;
         }
-        LB(H_HIST + 2) += 3;
-        if (!INDIRECT) LB(H_HIST + 2 + v0) -= 3;
-        sum -= 3 * v0;
+        hist_add(lp, 0, 3);
+        if (!INDIRECT) hist_add(lp, t0, -3);
+        sum -= 3 * t0;
         top = 0;
         any = true;
       }
@@ -433,27 +567,26 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
     if (any) LB(P.L.off_refunded + p)++;  // +1 per action, not per column (skyjo.py:418-419)
   }
   LSH(P.L.off_sums + 2 * p) = (int16_t)sum;
+  LB(P.L.off_hidden + p) = (uint8_t)hid;
   LH(P.L.off_placed + 2 * p)++;
-  LB(H_NDISC) = (uint8_t)ns;
-  LB(H_TOP) = (uint8_t)top;
-  LB(H_HAND) = SKYJO_HAND_NONE;
-  LB(H_PHASE) = 0;
-  LB(H_PLAYER) = (uint8_t)(p + 1 == N ? 0 : p + 1);  // skyjo.py:114-120,142-144
-  refresh_minima(P, lp);
+  const int ms = sum < oms ? sum : oms, mh = hid < omh ? hid : omh;
+  LB(H_MINSUM) = (uint8_t)(int8_t)(ms < 127 ? ms : 127);
+  LB(H_MINHID) = (uint8_t)mh;
+  h.w1 = (h.w1 & 0x00ff00ffu) | ((uint32_t)ns << 8) | (((uint32_t)top & 0xffu) << 24);
+  h.w2 = (h.w2 & 0x00ffffffu) | ((uint32_t)SKYJO_HAND_NONE << 24);
+  const int np = p + 1 == N ? 0 : p + 1;  // skyjo.py:114-120,142-144
+  h.w0 = (h.w0 & 0xffff0000u) | ((uint32_t)np << 8);  // phase = draw
 }
 
 // ------------------------------------------------------------------------------------------
 // collect_observation (skyjo.py:148-199) + action mask (skyjo.py:201-224) -> output record.
-// obs[0..18] are a straight copy of state bytes 16..34; the card part is the observer's `vis`
-// row (indirect) or all rows in absolute seat order (direct, skyjo.py:279-302).
+// obs[0..16] are a straight copy of state bytes 16..32, obs[17] / obs[18] come from the header
+// registers; the card part is the observer's `vis` row (indirect) or all rows in absolute seat
+// order (direct, skyjo.py:279-302).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t swar_nonzero01(uint32_t x) {
-  return ((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u) >> 7;
-}
-
 template <bool INDIRECT>
-__device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, int q, uint8_t *out) {
-  const int phase = LB(H_PHASE);
+__device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, const HdrRegs &h, int q, uint8_t *out) {
+  const int phase = h.w0 & 0xff;
   const int vq = (P.L.off_vis + 12 * q) >> 2;
   const uint32_t q0 = LW(vq), q1 = LW(vq + 1), q2 = LW(vq + 2);
   uint32_t m[8];
@@ -465,10 +598,11 @@ __device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, int 
     m[3] = (swar_nonzero01(q0 ^ 0x0f0f0f0fu) ^ 0x01010101u) & pm;  // vis == 15 <=> players_masked == 2
     m[4] = (swar_nonzero01(q1 ^ 0x0f0f0f0fu) ^ 0x01010101u) & pm;
     m[5] = (swar_nonzero01(q2 ^ 0x0f0f0f0fu) ^ 0x01010101u) & pm;
-    m[6] = (phase ? 0u : 0x0101u) | ((uint32_t)LB(H_PLAYER) << 16) | ((uint32_t)phase << 24);
-    m[7] = ((LB(H_FLAGS) & F_DONE) ? 1u : 0u) | ((uint32_t)LB(H_STATUS) << 8) | ((uint32_t)LH(H_EPLEN) << 16);
+    m[6] = (phase ? 0u : 0x0101u) | (((h.w0 >> 8) & 0xffu) << 16) | ((uint32_t)phase << 24);
+    m[7] = (((h.w0 >> 16) & F_DONE) ? 1u : 0u) | ((h.w0 >> 24) << 8) | ((h.w2 & 0xffffu) << 16);
   }
-  const uint32_t s8 = LW(8) & 0x00ffffffu;
+  // obs[16] = hist[14], obs[17] = discard top, obs[18] = hand card
+  const uint32_t s8 = (LW(8) & 0xffu) | ((h.w1 >> 24) << 8) | ((h.w2 >> 24) << 16);
   if (INDIRECT) {
     uint4 *o = (uint4 *)out;
     uint4 a, b;
@@ -494,40 +628,34 @@ __device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, int 
   }
 }
 
-// uniform choice over the legal actions == policy_ra's p = mask / sum(mask)
-// (rlskyjo/models/random_admissible_policy.py:26-28); word = Philox4x32-10 output for this
-// (game, iteration), k = mulhi(word, n_legal), action = k-th legal action in ascending order.
-__device__ __forceinline__ int policy_pick(const SkParams &P, uint8_t *lp, uint32_t word) {
-  if (LB(H_PHASE) == 0) return 24 + (int)__umulhi(word, 2u);
-  const int vq = (P.L.off_vis + 12 * LB(H_PLAYER)) >> 2;
-  const uint32_t q0 = LW(vq), q1 = LW(vq + 1), q2 = LW(vq + 2);
-  auto pack = [](uint32_t a, uint32_t b, uint32_t c) -> uint32_t {  // 0/1 bytes -> 12 bits
-    uint32_t r = 0;
-    r |= (a * 0x00204081u >> 21) & 0xfu;  // gather bit0 of each byte: b0 | b8>>7 | b16>>14 | b24>>21
-    r |= ((b * 0x00204081u >> 21) & 0xfu) << 4;
-    r |= ((c * 0x00204081u >> 21) & 0xfu) << 8;
-    return r;
-  };
-  uint32_t legal = pack(swar_nonzero01(q0 ^ 0xf2f2f2f2u), swar_nonzero01(q1 ^ 0xf2f2f2f2u),
-                        swar_nonzero01(q2 ^ 0xf2f2f2f2u)) |
-                   (pack(swar_nonzero01(q0 ^ 0x0f0f0f0fu) ^ 0x01010101u, swar_nonzero01(q1 ^ 0x0f0f0f0fu) ^ 0x01010101u,
-                         swar_nonzero01(q2 ^ 0x0f0f0f0fu) ^ 0x01010101u)
-                    << 12);
-  const int n = __popc(legal);
-  if (n == 0) return 24;
-  int k = (int)__umulhi(word, (uint32_t)n);
-  for (; k > 0; k--) legal &= legal - 1;
-  return __ffs((int)legal) - 1;
-}
-
 // ------------------------------------------------------------------------------------------
 // Take the pre-dealt next episode (SkyjoGame.reset, skyjo.py:52-74; the dealing itself is k_deal).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, int tile, int lane, int g) {
+  const uint4 *s = P.spare + (size_t)tile * P.L.chunks * SK_TILE + lane;
+  const int n = P.L.chunks;
+  // flags and the first 9 chunks are requested together (the record is read even if it turns out not to be ready)
   const uint8_t ready = P.spare_ready[g], sel = P.rng_sel[g];
   const uint32_t dc = P.deals_consumed[g];
+  uint4 v[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++)
+    if (k < n) v[k] = s[(size_t)k * SK_TILE];
   if (!ready) return false;
-  tile_load(P, P.spare, tile, lane, lp);
+#pragma unroll
+  for (int k = 0; k < 9; k++)
+    if (k < n) LW(4 * k + 0) = v[k].x, LW(4 * k + 1) = v[k].y, LW(4 * k + 2) = v[k].z, LW(4 * k + 3) = v[k].w;
+  for (int c = 9; c < n; c += 9) {
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+      if (c + k < n) v[k] = s[(size_t)(c + k) * SK_TILE];
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+      if (c + k < n) {
+        const int w = 4 * (c + k);
+        LW(w + 0) = v[k].x, LW(w + 1) = v[k].y, LW(w + 2) = v[k].z, LW(w + 3) = v[k].w;
+      }
+  }
   P.spare_ready[g] = 0;  // k_deal finds the empty slots with a ballot scan
   P.rng_sel[g] = sel ^ 1;
   P.deals_consumed[g] = dc + 1;
@@ -551,8 +679,14 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams P, const int32_t *act
   const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
   uint8_t *fp = lp + P.L.chunks * 1024;  // 16-word per-lane scratch behind the tile (RNG FIFO)
+  uint8_t *ap = (uint8_t *)lds_raw + P.L.chunks * 1024 + 4096 + lane * 8;  // 2N float64 accumulators per lane
+  for (int k = 0; k < 2 * P.L.N; k++) ACC(k) = 0.0;
+  STAMP_DECL;
   tile_load(P, P.state, tile, lane, lp);
-  const bool valid = (LB(H_FLAGS) & F_VALID) != 0;
+  HdrRegs h;
+  HDR_LOAD(h);
+  STAMP(0);
+  const bool valid = ((h.w0 >> 16) & F_VALID) != 0;
   LaneCounters cnt;
   uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
   const uint64_t gid = P.game_id0 + (uint64_t)g;
@@ -563,48 +697,68 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams P, const int32_t *act
                     (uint32_t)(policy_seed >> 32), r0, r1, r2, r3);
     int a = -1;
     if (valid) {
-      if (LB(H_FLAGS) & F_DONE) {
+      if ((h.w0 >> 16) & F_DONE) {
         if (P.auto_reset) {
           if (!consume_spare(P, lp, tile, lane, g)) {
+#ifndef SK_EXPERIMENT_NO_RARE
             deal_inline(P, lp, fp, g);
+#endif
             cnt.waits++;  // counts the slow-path deals
           }
-          LB(H_STATUS) = SKYJO_ST_RESET;
+          HDR_LOAD(h);
+          h.w0 = (h.w0 & 0x00ffffffu) | ((uint32_t)SKYJO_ST_RESET << 24);
           cnt.resets++;
         } else {
-          LB(H_STATUS) = SKYJO_ST_NOOP_DONE;
+          h.w0 = (h.w0 & 0x00ffffffu) | ((uint32_t)SKYJO_ST_NOOP_DONE << 24);
         }
+        STAMP(1);
       } else {
+        const int vw = (P.L.off_vis + 12 * (int)((h.w0 >> 8) & 0xff)) >> 2;
+        const uint32_t v0 = LW(vw), v1 = LW(vw + 1), v2 = LW(vw + 2);
+        STAMP(2);
         if (POLICY) {
           const uint32_t sel = (uint32_t)(iter & 3);
-          a = policy_pick(P, lp, sel == 0 ? r0 : sel == 1 ? r1 : sel == 2 ? r2 : r3);
+          a = policy_pick(h.w0 & 0xff, v0, v1, v2, sel == 0 ? r0 : sel == 1 ? r1 : sel == 2 ? r2 : r3);
         } else {
           a = actions[g];
         }
-        apply_action<INDIRECT>(P, lp, fp, a, g, cnt);
+        STAMP(3);
+        apply_action<INDIRECT>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st);
+        STAMP(5);
       }
       if (rec_out)
-        emit_record<INDIRECT>(P, lp, LB(H_PLAYER), rec_out + ((size_t)it * P.B + g) * (size_t)P.L.rec_bytes);
+        emit_record<INDIRECT>(P, lp, h, (h.w0 >> 8) & 0xff, rec_out + ((size_t)it * P.B + g) * (size_t)P.L.rec_bytes);
       if (act_out) act_out[(size_t)it * P.B + g] = a;
+      STAMP(6);
     }
   }
+  HDR_FLUSH(h);
   tile_store(P, P.state, tile, lane, lp);
-  // one atomic per counter per wave
+  // per-wavefront event counts go to the tile's own slot: thousands of same-address atomics at the
+  // end of a launch would serialise at ~12 ns each (MI355X_MICROARCH.md, "fanin")
   uint32_t v[7] = {cnt.steps, cnt.episodes, cnt.illegal, cnt.resets, cnt.sum_len, cnt.reshuffles, cnt.waits};
 #pragma unroll
   for (int k = 0; k < 7; k++)
     for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
   if (lane == 0) {
-    unsigned long long *c = &P.counters->steps;
-    if (v[0]) atomicAdd(&c[0], (unsigned long long)v[0]);
-    if (v[1]) atomicAdd(&c[1], (unsigned long long)v[1]);
-    if (v[2]) atomicAdd(&c[2], (unsigned long long)v[2]);
-    if (v[3]) atomicAdd(&c[3], (unsigned long long)v[3]);
-    if (v[4]) atomicAdd(&c[4], (unsigned long long)v[4]);
-    if (v[5]) atomicAdd(&c[5], (unsigned long long)v[5]);
-    if (v[6]) atomicAdd(&c[7], (unsigned long long)v[6]);
-    if (tile == 0) atomicAdd(&c[6], (unsigned long long)iters);
+    unsigned long long *c = P.tile_counters + (size_t)tile * 8;
+#pragma unroll
+    for (int k = 0; k < 7; k++) c[k] += v[k];
   }
+  // per-seat score / reward sums of this launch: wavefront reduction, then one slot per tile
+  if (__any(cnt.episodes | cnt.illegal)) {
+    double mine = 0.0;
+    for (int k = 0; k < 2 * P.L.N; k++) {
+      double x = ACC(k);
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      x = __shfl(x, 0, 64);
+      mine = lane == k ? x : mine;
+    }
+    if (lane < 2 * P.L.N)  // scores in slots 0..11, rewards in 12..23
+      P.acc_tile[(size_t)tile * 2 * SKYJO_MAX_PLAYERS + (lane < P.L.N ? lane : SKYJO_MAX_PLAYERS + lane - P.L.N)] += mine;
+  }
+  STAMP(7);
+  STAMP_STORE;
 }
 
 // SimpleSkyjoEnv.observe(agent) (skyjo_env.py:199-214) for arbitrary players; state untouched.
@@ -615,9 +769,11 @@ __global__ __launch_bounds__(SK_TILE) void k_observe(SkParams P, const int32_t *
   uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
   tile_load(P, P.state, tile, lane, lp);
   if (!(LB(H_FLAGS) & F_VALID)) return;
+  HdrRegs h;
+  HDR_LOAD(h);
   int q = players ? players[g] : LB(H_PLAYER);
   q = q < 0 ? 0 : (q >= P.L.N ? P.L.N - 1 : q);
-  emit_record<INDIRECT>(P, lp, q, rec_out + (size_t)g * P.L.rec_bytes);
+  emit_record<INDIRECT>(P, lp, h, q, rec_out + (size_t)g * P.L.rec_bytes);
 }
 
 // SkyjoGame.reset for the masked games: take the pre-dealt episode.
@@ -634,11 +790,14 @@ __global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *ma
     took = true;
     if (!consume_spare(P, lp, tile, lane, g)) deal_inline(P, lp, fp, g);
     LB(H_STATUS) = SKYJO_ST_RESET;
-    atomicAdd(&P.counters->resets, 1ull);
   }
   if (!took) tile_load(P, P.state, tile, lane, lp);
-  if (rec_out) emit_record<INDIRECT>(P, lp, LB(H_PLAYER), rec_out + (size_t)g * P.L.rec_bytes);
+  HdrRegs h;
+  HDR_LOAD(h);
+  if (rec_out) emit_record<INDIRECT>(P, lp, h, LB(H_PLAYER), rec_out + (size_t)g * P.L.rec_bytes);
   if (want) tile_store(P, P.state, tile, lane, lp);
+  const unsigned long long wb = __ballot(want);
+  if (want && lane == __ffsll((long long)wb) - 1) P.tile_counters[(size_t)tile * 8 + 3] += __popcll(wb);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -791,7 +950,13 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int all) {
       for (int l = 0; l < n_act; l++) {  // cooperative, coalesced copy of one 2496-byte state per step
         const uint32_t *sp = (const uint32_t *)__shfl(src, l, 64);
         uint32_t *dp = (uint32_t *)__shfl(dst, l, 64);
-        for (int k = lane; k < 624; k += SK_TILE) dp[k] = sp[k];
+        uint32_t t[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++)
+          if (lane + 64 * k < 624) t[k] = sp[lane + 64 * k];
+#pragma unroll
+        for (int k = 0; k < 10; k++)
+          if (lane + 64 * k < 624) dp[lane + 64 * k] = t[k];
       }
       __syncthreads();
       if (act) {
@@ -815,16 +980,26 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int all) {
 
 // per-seat sums over all games for skyjo_vec_get_counters (the hot path keeps per-game sums, no atomics)
 __global__ void k_reduce_stats(SkParams P) {
-  const int N = P.L.N;
-  for (int p = 0; p < N; p++) {
+  for (int p = 0; p < P.L.N; p++) {
     double a = 0.0, b = 0.0;
-    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < P.B; g += gridDim.x * blockDim.x)
-      a += P.acc_score[(size_t)g * N + p], b += P.acc_reward[(size_t)g * N + p];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.tiles; i += gridDim.x * blockDim.x) {
+      a += P.acc_tile[(size_t)i * 2 * SKYJO_MAX_PLAYERS + p];
+      b += P.acc_tile[(size_t)i * 2 * SKYJO_MAX_PLAYERS + SKYJO_MAX_PLAYERS + p];
+    }
     for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64), b += __shfl_down(b, off, 64);
     if ((threadIdx.x & 63) == 0) {
       atomicAdd(&P.counters->sum_score[p], a);
       atomicAdd(&P.counters->sum_reward[p], b);
     }
+  }
+  // order of SkCounters' leading fields: steps, episodes, illegal, resets, sum_len, reshuffles, iters, waits
+  const int dst[7] = {0, 1, 2, 3, 4, 5, 7};
+  for (int k = 0; k < 7; k++) {
+    unsigned long long t = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.tiles; i += gridDim.x * blockDim.x)
+      t += P.tile_counters[(size_t)i * 8 + k];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if ((threadIdx.x & 63) == 0 && t) atomicAdd(&(&P.counters->steps)[dst[k]], t);
   }
 }
 

@@ -15,6 +15,7 @@
 #define SK_NCARDS 150
 
 // ---- fixed header (bytes) ----
+// words 0..2 are the hot fields: the step kernel keeps them in three registers for a whole launch
 #define H_PHASE 0     // 0 draw, 1 place              (expected_action[1], skyjo.py:144)
 #define H_PLAYER 1    // expected player              (expected_action[0])
 #define H_FLAGS 2     // F_* bits
@@ -22,17 +23,16 @@
 #define H_NDRAW 4     // len(drawpile)
 #define H_NDISC 5     // len(discard_pile)
 #define H_ROLE 6      // which end of the pile buffer holds the draw pile (flips at a reshuffle)
-#define H_FINISHER 7
+#define H_TOP 7       // discard top or -3            (skyjo.py:254)  -> obs[17]
 #define H_EPLEN 8     // u16 steps in this episode
 #define H_RESH 10     // reshuffles in this episode (saturating)
-#define H_RNGSEL 11   // which of the two MT19937 buffers is current
+#define H_HAND 11     // hand card or 15              (skyjo.py:61)   -> obs[18]
 #define H_EPISODE 12  // u32 deal index of the live episode
-// bytes 16.. are laid out so that obs[k] == state[16 + k] for k < 19 (skyjo.py:180-186)
+// bytes 16..32 are laid out so that obs[k] == state[16 + k] for k < 17 (skyjo.py:180-184)
 #define H_MINSUM 16   // min(min_p revealed_sum_p, 127)
 #define H_MINHID 17   // min_p hidden_count_p
-#define H_HIST 18     // u8[15] bincount of values -2..12
-#define H_TOP 33      // discard top or -3            (skyjo.py:254)
-#define H_HAND 34     // hand card or 15              (skyjo.py:61)
+#define H_HIST 18     // u8[15] bincount of values -2..12 (updated with dword LDS atomics)
+#define H_FINISHER 33
 #define H_END 36
 
 #define F_TERMINATED 1  // is_terminated (skyjo.py:54)

@@ -1,0 +1,22 @@
+"""Diagnostic: where does a k_step wavefront spend its cycles?  Needs a -DSK_STAMPS build:
+   hipcc ... -DSK_STAMPS -o /tmp/libskyjo_stamps.so ; SKYJO_LIB=/tmp/libskyjo_stamps.so python tools/stamps.py"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from skyjo_rl_amd import SkyjoVecEnv, _lib
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+eng = SkyjoVecEnv(B, num_players=3)
+eng.seed(None, 0)
+rec = eng.new_records(16); act = torch.empty((16, B), dtype=torch.int32, device="cuda")
+for _ in range(20): eng.rollout(16, 1, records=rec, actions=act)
+torch.cuda.synchronize()
+out = np.zeros(8, dtype=np.uint64)
+_lib.check(eng._L.skyjo_vec_debug_stamps(eng._h, out.ctypes.data_as(C.c_void_p)))
+for _ in range(10): eng.rollout(16, 1, records=rec, actions=act)
+torch.cuda.synchronize()
+_lib.check(eng._L.skyjo_vec_debug_stamps(eng._h, out.ctypes.data_as(C.c_void_p)))
+names = ["tile_load", "philox+reset path", "vis row load", "policy_pick", "apply: legality+draw(+finish)", "apply: place", "emit+stores", "tile_store+counters"]
+tot = float(out.sum()); waves = (B + 63) // 64 * 10
+for n, v in zip(names, out):
+    print("%-30s %6.1f%%  %9.0f cycles/wave/launch  %8.0f /iter" % (n, 100 * v / tot, v / waves, v / waves / 16))
+print("total cycles/wave/launch %.0f" % (tot / waves))
