@@ -180,9 +180,9 @@ int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream)
 int skyjo_vec_profile(skyjo_vec *h, int enable, double *step_ms, int64_t *step_launches, double *deal_ms,
                       int64_t *deal_launches);
 
-/* Diagnostic builds only (-DSK_STAMPS): per-section shader-cycle sums of the step kernel, summed over
- * wavefronts, cleared on read.  The shipped build returns zeros. */
-int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out8_host);
+/* Diagnostic builds only (-DSK_STAMPS): per-section shader-cycle sums, 8 for the step kernel followed by 8 for
+ * the dealing kernel, summed over wavefronts, cleared on read.  The shipped build returns zeros. */
+int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
 
 /* Tunables.  SKYJO_OPT_DEAL_INTERVAL: skyjo_vec_step launches between two runs of the dealing kernel
  * (1..64, default 1); a finished game whose next deal is not ready yet deals in place (slow path). */

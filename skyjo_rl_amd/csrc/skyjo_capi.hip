@@ -168,12 +168,12 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   int rc = SKYJO_OK;
   const size_t N = (size_t)cfg->num_players;
   if ((rc = dalloc(h, &P.state, rec16)) || (rc = dalloc(h, &P.spare, rec16)) ||
-      (rc = dalloc(h, &P.spare_ready, h->G)) || (rc = dalloc(h, &P.rng_sel, h->G)) ||
+      (rc = dalloc(h, &P.spare_ready, h->G)) ||
       (rc = dalloc(h, &P.mt_idx, 2 * h->G)) || (rc = dalloc(h, &P.seeds, h->G)) ||
       (rc = dalloc(h, &P.deals_consumed, h->G)) || (rc = dalloc(h, &P.rewards, h->G * N)) ||
       (rc = dalloc(h, &P.scores, h->G * N)) || (rc = dalloc(h, &P.done, h->G)) ||
       (rc = dalloc(h, &P.acc_tile, (size_t)P.tiles * 2 * SKYJO_MAX_PLAYERS)) ||
-      (rc = dalloc(h, &P.counters, 1)) || (rc = dalloc(h, &P.tile_counters, (size_t)P.tiles * 8)) || (rc = dalloc(h, &P.stamps, (size_t)P.tiles * 8))) {
+      (rc = dalloc(h, &P.counters, 1)) || (rc = dalloc(h, &P.tile_counters, (size_t)P.tiles * 8)) || (rc = dalloc(h, &P.stamps, (size_t)P.tiles * 16))) {
     skyjo_vec_destroy(h);
     return rc;
   }
@@ -430,10 +430,6 @@ int skyjo_vec_set_state(skyjo_vec *h, int32_t game, const skyjo_game_state *in, 
   return SKYJO_OK;
 }
 
-__global__ void k_invalidate_spare(SkParams P, int g) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) P.spare_ready[g] = 0;
-}
-
 int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream) {
   if (!h || game < 0 || game >= h->P.B) return fail(SKYJO_E_INVALID, "bad argument");
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
@@ -442,7 +438,6 @@ int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream)
   int rc;
   if (h->pending_deals > 0 && (rc = launch_deal(h, s, false))) return rc;
   hipLaunchKernelGGL(k_seed_raw, dim3(1), dim3(64), 0, s, h->P, game, value);
-  hipLaunchKernelGGL(k_invalidate_spare, dim3(1), dim3(64), 0, s, h->P, game);
   HIPCHK(hipGetLastError());
   return launch_deal(h, s, false);
 }
@@ -471,12 +466,13 @@ int skyjo_vec_profile(skyjo_vec *h, int enable, double *step_ms, int64_t *step_l
   return SKYJO_OK;
 }
 
-int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out8_host) {
-  if (!h || !out8_host) return fail(SKYJO_E_INVALID, "null argument");
-  std::vector<unsigned long long> t((size_t)h->P.tiles * 8);
+int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host) {
+  if (!h || !out16_host) return fail(SKYJO_E_INVALID, "null argument");
+  const size_t half = (size_t)h->P.tiles * 8;
+  std::vector<unsigned long long> t(2 * half);
   HIPCHK(hipMemcpy(t.data(), h->P.stamps, t.size() * 8, hipMemcpyDeviceToHost));
-  for (int k = 0; k < 8; k++) out8_host[k] = 0;
-  for (size_t i = 0; i < t.size(); i++) out8_host[i & 7] += t[i];
+  for (int k = 0; k < 16; k++) out16_host[k] = 0;
+  for (size_t i = 0; i < 2 * half; i++) out16_host[(i & 7) + (i >= half ? 8 : 0)] += t[i];  // [0,8) step, [8,16) deal
   HIPCHK(hipMemset(h->P.stamps, 0, t.size() * 8));
   return SKYJO_OK;
 }

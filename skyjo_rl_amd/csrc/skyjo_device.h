@@ -30,9 +30,8 @@ struct SkParams {
   uint4 *state;             // [tiles][chunks][64] live games
   uint4 *spare;             // [tiles][chunks][64] pre-dealt next episode of every game
   uint8_t *spare_ready;     // [tiles*64]
-  uint8_t *rng_sel;         // [tiles*64] which MT19937 buffer is current
-  uint32_t *mt;             // [2][tiles*64][624] numpy-legacy MT19937 state (MT mode only)
-  int32_t *mt_idx;          // [2][tiles*64]
+  uint32_t *mt;             // [2][tiles*64][624]: [0] numpy-legacy MT19937 state, [1] undo log of the pre-deal
+  int32_t *mt_idx;          // [2][tiles*64]: [0] stream position (idx | ahead << 16), [1] position before the pre-deal
   uint64_t *seeds;          // [tiles*64] value given to set_seed
   uint32_t *deals_consumed; // [tiles*64]
   double *rewards;          // [tiles*64][N]
@@ -95,6 +94,33 @@ __device__ __forceinline__ void tile_store(const SkParams &P, uint4 *dst, int ti
   }
 }
 
+// Diagnostic builds (-DSK_STAMPS) sum s_memtime deltas per section into P.stamps; the shipped build has none.
+struct Stamps {
+  unsigned long long t, acc[8];
+};
+#ifdef SK_STAMPS
+#define STAMP_DECL Stamps st; st.t = __builtin_amdgcn_s_memtime(); for (int k_ = 0; k_ < 8; k_++) st.acc[k_] = 0
+#define STAMP(i)                                                 \
+  do {                                                           \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    __builtin_amdgcn_s_waitcnt(0);                               \
+    unsigned long long st_n = __builtin_amdgcn_s_memtime();      \
+    __builtin_amdgcn_s_waitcnt(0);                               \
+    st.acc[i] += st_n - st.t;                                    \
+    st.t = st_n;                                                 \
+    __builtin_amdgcn_sched_barrier(0);                           \
+  } while (0)
+#define STAMP_STORE                                                        \
+  do {                                                                     \
+    if (lane == 0)                                                         \
+      for (int k = 0; k < 8; k++) P.stamps[(size_t)tile * 8 + k] += st.acc[k]; \
+  } while (0)
+#else
+#define STAMP_DECL Stamps st
+#define STAMP(i)
+#define STAMP_STORE
+#endif
+
 // ------------------------------------------------------------------------------------------
 // RNG.  MT mode restates numpy's legacy RandomState (requirements.txt:3 pins numpy==1.21.5; call
 // sites skyjo.py:81,94,101,135): init_genrand, tempering, rk_interval, Fisher-Yates.  The state
@@ -121,11 +147,13 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t v) {
 template <int DEPTH>
 struct MtStream {
   uint32_t *mt;
+  uint32_t *undo;  // DEPTH 64 only: old values of every regenerated element are kept here (same index)
   uint8_t *fp;
+  Stamps *stp = nullptr;  // diagnostics only
   int idx, gen, rp, wp, pend, used;
   __device__ __forceinline__ static int wrap(int x) { return x >= 624 ? x - 624 : x; }
-  __device__ __forceinline__ void open(uint32_t *mt_, int packed, uint8_t *fp_) {
-    mt = mt_, fp = fp_;
+  __device__ __forceinline__ void open(uint32_t *mt_, int packed, uint8_t *fp_, uint32_t *undo_ = nullptr) {
+    mt = mt_, fp = fp_, undo = undo_;
     idx = packed & 0xffff;
     idx = idx >= 624 ? 0 : idx;
     const int ahead = packed >> 16;
@@ -153,6 +181,7 @@ struct MtStream {
     for (int k = 0; k < 16; k++) {
       uint32_t y = (o[k] & 0x80000000u) | (o[k + 1] & 0x7fffffffu);
       uint32_t v = x[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      if (DEPTH >= 64) undo[c + k] = o[k];
       mt[c + k] = v;
       MT_FIFO((wp + k) & (DEPTH - 1)) = mt_temper(v);
     }
@@ -161,7 +190,21 @@ struct MtStream {
   }
   // called where the active lanes of the wavefront are converged: refill together when all have room
   __device__ __forceinline__ void service() {
-    if (DEPTH >= 64 && __all(DEPTH - (wp - rp) >= 16)) refill();
+    if (DEPTH >= 64 && __all(DEPTH - (wp - rp) >= 16)) {
+#ifdef SK_STAMPS
+      Stamps &st = *stp;
+      STAMP(3);
+      refill();
+      STAMP(5);
+#else
+      refill();
+#endif
+    }
+  }
+  __device__ __forceinline__ void unget() {  // give back the draw returned by the last next()
+    used--;
+    if (DEPTH < 64 && rp == 0 && wp == 0) pend++;  // still in the read-from-memory phase of open()
+    else rp--;
   }
   __device__ __forceinline__ uint32_t next() {
     uint32_t v;
@@ -199,6 +242,7 @@ struct PhiloxStream {
     k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32), blk = 0, c1 = episode, c2 = resh, c3 = domain, pos = 4;
   }
   __device__ __forceinline__ void service() {}
+  __device__ __forceinline__ void unget() { pos--; }  // pos >= 1 after any next()
   __device__ __forceinline__ uint32_t next() {
     if (pos >= 4) {
       philox4x32_10(blk, c1, c2, c3, k0, k1, b0, b1, b2, b3);
@@ -264,13 +308,23 @@ __device__ __forceinline__ void reshuffle_discard(const SkParams &P, uint8_t *lp
 __device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *lp, uint8_t *fp, int g) {
   if (P.rng_mode == SKYJO_RNG_MT19937) {
     const size_t G = (size_t)P.tiles * SK_TILE;
-    const int sel = P.rng_sel[g];
+    uint32_t *mt = P.mt + (size_t)g * 624;
+    int packed = P.mt_idx[g];
+    if (P.spare_ready[g]) {
+      // The pre-dealt next episode consumed the stream beyond this point (numpy draws the reshuffle first):
+      // roll the state back with the undo log, k_deal deals again afterwards.
+      const uint32_t *undo = P.mt + (G + g) * 624;
+      const int snap = P.mt_idx[G + g];
+      int from = (snap & 0xffff) + (snap >> 16), to = (packed & 0xffff) + (packed >> 16);
+      from = from >= 624 ? from - 624 : from, to = to >= 624 ? to - 624 : to;
+      for (int i = from; i != to; i = i + 1 == 624 ? 0 : i + 1) mt[i] = undo[i];
+      packed = snap;
+      P.spare_ready[g] = 0;
+    }
     MtStream<16> r;
-    r.open(P.mt + ((size_t)sel * G + g) * 624, P.mt_idx[(size_t)sel * G + g], fp);
+    r.open(mt, packed, fp);
     reshuffle_discard(P, lp, r);
-    P.mt_idx[(size_t)sel * G + g] = r.close();
-    // the pre-dealt next episode was drawn from the stream position before this reshuffle: k_deal redoes it
-    P.spare_ready[g] = 0;
+    P.mt_idx[g] = r.close();
   } else {
     PhiloxStream r;
     r.open(P.seeds[g] + 1, *(uint32_t *)(lp + LIDX(H_EPISODE)), LB(H_RESH), 1u);
@@ -334,33 +388,6 @@ __device__ __forceinline__ void finish_game(const SkParams &P, uint8_t *lp, uint
 // Histogram bins are bumped with fire-and-forget dword LDS atomics (bin k is byte k & 3 of its
 // word; counts stay far below 256 so no carry crosses a byte).
 // ------------------------------------------------------------------------------------------
-// Diagnostic builds (-DSK_STAMPS) sum s_memtime deltas per section into P.stamps; the shipped build has none.
-struct Stamps {
-  unsigned long long t, acc[8];
-};
-#ifdef SK_STAMPS
-#define STAMP_DECL Stamps st; st.t = __builtin_amdgcn_s_memtime(); for (int k_ = 0; k_ < 8; k_++) st.acc[k_] = 0
-#define STAMP(i)                                                 \
-  do {                                                           \
-    __builtin_amdgcn_sched_barrier(0);                           \
-    __builtin_amdgcn_s_waitcnt(0);                               \
-    unsigned long long st_n = __builtin_amdgcn_s_memtime();      \
-    __builtin_amdgcn_s_waitcnt(0);                               \
-    st.acc[i] += st_n - st.t;                                    \
-    st.t = st_n;                                                 \
-    __builtin_amdgcn_sched_barrier(0);                           \
-  } while (0)
-#define STAMP_STORE                                                        \
-  do {                                                                     \
-    if (lane == 0)                                                         \
-      for (int k = 0; k < 8; k++) P.stamps[(size_t)tile * 8 + k] += st.acc[k]; \
-  } while (0)
-#else
-#define STAMP_DECL Stamps st
-#define STAMP(i)
-#define STAMP_STORE
-#endif
-
 struct HdrRegs {
   uint32_t w0, w1, w2;  // bytes 0..3, 4..7, 8..11 of the record (skyjo_layout.h)
 };
@@ -635,7 +662,7 @@ __device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, in
   const uint4 *s = P.spare + (size_t)tile * P.L.chunks * SK_TILE + lane;
   const int n = P.L.chunks;
   // flags and the first 9 chunks are requested together (the record is read even if it turns out not to be ready)
-  const uint8_t ready = P.spare_ready[g], sel = P.rng_sel[g];
+  const uint8_t ready = P.spare_ready[g];
   const uint32_t dc = P.deals_consumed[g];
   uint4 v[9];
 #pragma unroll
@@ -657,7 +684,6 @@ __device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, in
       }
   }
   P.spare_ready[g] = 0;  // k_deal finds the empty slots with a ballot scan
-  P.rng_sel[g] = sel ^ 1;
   P.deals_consumed[g] = dc + 1;
   P.done[g] = 0;
   return true;
@@ -810,7 +836,6 @@ __global__ void k_seed(SkParams P, const uint64_t *seeds, uint64_t base, int fir
   const uint64_t value = seeds ? seeds[i] : base + P.game_id0 + (uint64_t)g;
   const size_t G = (size_t)P.tiles * SK_TILE;
   P.seeds[g] = value;
-  P.rng_sel[g] = 0;
   P.deals_consumed[g] = 0;
   P.spare_ready[g] = 0;
   if (P.rng_mode == SKYJO_RNG_MT19937) {
@@ -829,16 +854,15 @@ __global__ void k_seed(SkParams P, const uint64_t *seeds, uint64_t base, int fir
 // np.random.seed(value) on the CURRENT stream of one game, no +1, no deal (fixture injection)
 __global__ void k_seed_raw(SkParams P, int g, uint32_t value) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const size_t G = (size_t)P.tiles * SK_TILE;
-  const int sel = P.rng_sel[g];
-  uint32_t *mt = P.mt + ((size_t)sel * G + g) * 624;
+  uint32_t *mt = P.mt + (size_t)g * 624;
   uint32_t x = value;
   mt[0] = x;
   for (int k = 1; k < 624; k++) {
     x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)k;
     mt[k] = x;
   }
-  P.mt_idx[(size_t)sel * G + g] = 0;
+  P.mt_idx[g] = 0;
+  P.spare_ready[g] = 0;  // whatever was pre-dealt belongs to the old stream
 }
 
 // ------------------------------------------------------------------------------------------
@@ -846,14 +870,29 @@ __global__ void k_seed_raw(SkParams P, int g, uint32_t value) {
 // the games whose spare record is empty, one lane per game, written to the game's SPARE record.
 // RNG order per deal: shuffle(150) -> shuffle(150-12N) -> N x permutation(12)[:2].
 // ------------------------------------------------------------------------------------------
+// Legacy RandomState.shuffle: for i = n-1 .. 1: j = rk_interval(i); swap(a[i], a[j]).  Every lane walks
+// its own i, so a loop iteration is one draw for every lane (a rejected draw just does not advance i):
+// the trip count is the largest per-lane draw total, not the sum over i of the unluckiest lane's
+// rejections.  The draw for the next iteration is fetched before the swap to overlap the LDS round trips.
 template <class Rng>
 __device__ __forceinline__ void shuffle_lds(uint8_t *lp, int base, int n, Rng &r) {
-  for (int i = n - 1; i >= 1; i--) {
+  int i = n - 1;
+  if (i < 1) return;
+  uint32_t mask = 0xffffffffu >> __clz(i);
+  r.service();
+  uint32_t pre = r.next();
+  while (i >= 1) {
+    const uint32_t v = pre & mask;
     r.service();
-    int j = (int)rng_interval(r, (uint32_t)i);
-    uint8_t t = LB(base + i);
-    LB(base + i) = LB(base + j), LB(base + j) = t;
+    pre = r.next();
+    if (v <= (uint32_t)i) {
+      const uint8_t t = LB(base + i);
+      LB(base + i) = LB(base + (int)v), LB(base + (int)v) = t;
+      i--;
+      mask = 0xffffffffu >> __clz(i | 1);
+    }
   }
+  r.unget();  // the prefetched draw belongs to whoever consumes the stream next
 }
 
 template <class Rng>
@@ -901,12 +940,10 @@ __device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rn
 __device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g) {
   const uint32_t ep = P.deals_consumed[g];
   if (P.rng_mode == SKYJO_RNG_MT19937) {
-    const size_t G = (size_t)P.tiles * SK_TILE;
-    const int sel = P.rng_sel[g];
     MtStream<16> r;
-    r.open(P.mt + ((size_t)sel * G + g) * 624, P.mt_idx[(size_t)sel * G + g], fp);
+    r.open(P.mt + (size_t)g * 624, P.mt_idx[g], fp);
     deal_into_lds(P, lp, r, ep);
-    P.mt_idx[(size_t)sel * G + g] = r.close();
+    P.mt_idx[g] = r.close();
   } else {
     PhiloxStream r;
     r.open(P.seeds[g] + 1, ep, 0u, 0u);
@@ -928,6 +965,9 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int all) {
   int32_t *work = (int32_t *)((uint8_t *)lds_raw + P.L.chunks * 1024 + 16384);  // behind the 64-word rings
   const size_t G = (size_t)P.tiles * SK_TILE;
   const int g0 = blockIdx.x * SK_DEAL_SPAN;
+  const int tile = blockIdx.x;  // stamp slot
+  (void)tile;
+  STAMP_DECL;
   int count = 0;
   for (int base = 0; base < SK_DEAL_SPAN; base += SK_TILE) {
     const int g = g0 + base + lane;
@@ -937,33 +977,34 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int all) {
     count += __popcll(b);
   }
   __syncthreads();
+  STAMP(0);
   for (int base = 0; base < count; base += SK_TILE) {
     const bool act = base + lane < count;
     const int g = act ? work[base + lane] : 0;
+    bool mt_overrun = false;
     if (P.rng_mode == SKYJO_RNG_MT19937) {
-      // continue the game's stream in the OTHER buffer, so a mid-game reshuffle of the live episode
-      // can still advance the current one and have this deal redone (reshuffle_dispatch)
-      const int sel = act ? P.rng_sel[g] : 0;
-      const unsigned long long src = (unsigned long long)(P.mt + ((size_t)sel * G + g) * 624);
-      const unsigned long long dst = (unsigned long long)(P.mt + ((size_t)(sel ^ 1) * G + g) * 624);
-      const int n_act = count - base < SK_TILE ? count - base : SK_TILE;
-      for (int l = 0; l < n_act; l++) {  // cooperative, coalesced copy of one 2496-byte state per step
-        const uint32_t *sp = (const uint32_t *)__shfl(src, l, 64);
-        uint32_t *dp = (uint32_t *)__shfl(dst, l, 64);
-        uint32_t t[10];
-#pragma unroll
-        for (int k = 0; k < 10; k++)
-          if (lane + 64 * k < 624) t[k] = sp[lane + 64 * k];
-#pragma unroll
-        for (int k = 0; k < 10; k++)
-          if (lane + 64 * k < 624) dp[lane + 64 * k] = t[k];
-      }
-      __syncthreads();
+      // The stream advances in place; the old value of every regenerated element goes to the undo log so
+      // that a mid-game reshuffle of the live episode (which numpy would have drawn BEFORE this deal) can
+      // roll the stream back and have this deal redone (reshuffle_dispatch).
       if (act) {
+        const int packed = P.mt_idx[g];
+        P.mt_idx[G + g] = packed;
         MtStream<64> r;
-        r.open((uint32_t *)dst, P.mt_idx[(size_t)sel * G + g], fp);
+        r.open(P.mt + (size_t)g * 624, packed, fp, P.mt + (G + g) * 624);
+        r.stp = &st;
+        STAMP(2);
         deal_into_lds(P, lp, r, P.deals_consumed[g]);
-        P.mt_idx[(size_t)(sel ^ 1) * G + g] = r.close();
+        P.mt_idx[g] = r.close();
+        mt_overrun = r.wp - (packed >> 16) > 624 - 64;  // undo log wrapped: give this speculation up
+        if (mt_overrun) {
+          uint32_t *mt = P.mt + (size_t)g * 624;
+          const uint32_t *undo = P.mt + (G + g) * 624;
+          int i = (packed & 0xffff) + (packed >> 16);
+          i = i >= 624 ? i - 624 : i;
+          for (int k = 0; k < 624; k++, i = i + 1 == 624 ? 0 : i + 1) mt[i] = undo[i];  // oldest values win
+          P.mt_idx[g] = packed;
+        }
+        STAMP(3);
       }
     } else if (act) {
       PhiloxStream r;
@@ -971,11 +1012,16 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int all) {
       r.open(P.seeds[g] + 1, ep, 0u, 0u);
       deal_into_lds(P, lp, r, ep);
     }
-    if (act) {
+    if (act && !mt_overrun) {  // (an overrun game deals in place when its episode ends: deal_inline)
       tile_store(P, P.spare, g / SK_TILE, g % SK_TILE, lp);
       P.spare_ready[g] = 1;
+      STAMP(4);
     }
   }
+#ifdef SK_STAMPS
+  if (lane == 0)
+    for (int k = 0; k < 8; k++) P.stamps[(size_t)(P.tiles + tile) * 8 + k] += st.acc[k];
+#endif
 }
 
 // per-seat sums over all games for skyjo_vec_get_counters (the hot path keeps per-game sums, no atomics)

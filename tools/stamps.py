@@ -10,13 +10,17 @@ eng.seed(None, 0)
 rec = eng.new_records(16); act = torch.empty((16, B), dtype=torch.int32, device="cuda")
 for _ in range(20): eng.rollout(16, 1, records=rec, actions=act)
 torch.cuda.synchronize()
-out = np.zeros(8, dtype=np.uint64)
+out = np.zeros(16, dtype=np.uint64)
 _lib.check(eng._L.skyjo_vec_debug_stamps(eng._h, out.ctypes.data_as(C.c_void_p)))
 for _ in range(10): eng.rollout(16, 1, records=rec, actions=act)
 torch.cuda.synchronize()
 _lib.check(eng._L.skyjo_vec_debug_stamps(eng._h, out.ctypes.data_as(C.c_void_p)))
 names = ["tile_load", "philox+reset path", "vis row load", "policy_pick", "apply: legality+draw(+finish)", "apply: place", "emit+stores", "tile_store+counters"]
-tot = float(out.sum()); waves = (B + 63) // 64 * 10
-for n, v in zip(names, out):
+dn = ["scan+compact", "-", "stream open", "deal_into_lds (shuffles etc.)", "tile_store", "MT refill (wave-synchronous)", "-", "-"]
+dt = float(out[8:].sum()); dwaves = (B + 255) // 256 * 10
+for n, v in zip(dn, out[8:]):
+    print("deal %-25s %6.1f%%  %9.0f cycles/wave/launch" % (n, 100 * v / max(dt, 1), v / dwaves))
+tot = float(out[:8].sum()); waves = (B + 63) // 64 * 10
+for n, v in zip(names, out[:8]):
     print("%-30s %6.1f%%  %9.0f cycles/wave/launch  %8.0f /iter" % (n, 100 * v / tot, v / waves, v / waves / 16))
 print("total cycles/wave/launch %.0f" % (tot / waves))
