@@ -133,14 +133,19 @@ def main():
     steps_total = float(allstats[:, 0].sum())
     t_max = float(allstats[:, 6].max())
 
-    # roofline leg: the same launches again with HIP events around every k_step launch
-    eng.profile(True)
-    run(10 * CHUNK)
-    prof = eng.profile(False)
+    # roofline leg: the same launches again, each k_step launch carrying a HIP event pair that receives the
+    # kernel's begin / end timestamps on its launch stream (comparable with rocprofv3's kernel trace, profiles/)
+    eng.profile(1)
+    run(32 * CHUNK)
+    prof = eng.profile(0)
     full = prof["step_launches"]
     avg_ms = prof["step_ms"] / max(full, 1)
     alg = algorithmic_bytes_per_launch(B, N, D, CHUNK, actions=record)
     achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
+    if os.path.exists(tpath) and B == 65536 and N == 3 and record:
+        traffic = json.load(open(tpath)).get("k_step_bytes_per_launch")
 
     if rank == 0:
         episodes = float(allstats[:, 1].sum())
@@ -166,7 +171,7 @@ def main():
             "episodes": episodes,
             "waits": float(allstats[:, 4].sum()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_step<indirect,policy>", "avg_launch_ms": avg_ms, "launches_timed": full,
                          "algorithmic_bytes_per_launch": alg,
                          "deal_kernel_avg_ms": prof["deal_ms"] / max(prof["deal_launches"], 1)},

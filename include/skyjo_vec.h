@@ -174,9 +174,10 @@ int skyjo_vec_set_state(skyjo_vec *h, int32_t game, const skyjo_game_state *in_h
 /* np.random.seed(value) on one game's legacy stream without dealing (fixture injection) */
 int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream);
 
-/* Per-launch timing with HIP events recorded on the launch stream.  Returns and clears what was collected
- * since the last call (sum of milliseconds and launch counts of the step/rollout kernel and of the dealing
- * kernel), then switches collection on/off.  Synchronises the device. */
+/* Kernel timing with HIP events on the launch stream: while enabled, every step / dealing kernel is launched
+ * with a (start, stop) event pair that receives the kernel's own begin and end timestamps.  Returns and clears
+ * what was collected since the last call (sum of milliseconds and launch counts per kernel), then switches
+ * collection on (1) or off (0).  Synchronises the device. */
 int skyjo_vec_profile(skyjo_vec *h, int enable, double *step_ms, int64_t *step_launches, double *deal_ms,
                       int64_t *deal_launches);
 
@@ -187,6 +188,9 @@ int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
 /* Tunables.  SKYJO_OPT_DEAL_INTERVAL: skyjo_vec_step launches between two runs of the dealing kernel
  * (1..64, default 1); a finished game whose next deal is not ready yet deals in place (slow path). */
 #define SKYJO_OPT_DEAL_INTERVAL 1
+/* SKYJO_OPT_ROLLOUT_DEAL_EVERY: step-kernel launches (16 iterations each) between two dealing-kernel launches
+ * inside skyjo_vec_rollout (1..16, default 1). */
+#define SKYJO_OPT_ROLLOUT_DEAL_EVERY 2
 int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value);
 
 /* host-pointer conveniences for small batches (single-game AEC view): synchronous */

@@ -1,6 +1,7 @@
 // skyjo_capi.hip - host side of libskyjo_vec.so: the extern "C" boundary declared in
 // include/skyjo_vec.h, handle / memory management and kernel launches.  gfx950 only, no CPU path.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +41,7 @@ struct skyjo_vec {
   bool seeded = false;
   int pending_deals = 0;  // step launches since the dealing kernel last ran
   int deal_interval = 1;
+  int rollout_deal_every = 1;  // k_step launches between two k_deal launches inside skyjo_vec_rollout
   uint64_t iter = 0;        // rollout iterations (the policy's Philox counter)
   uint64_t iters_total = 0; // lockstep iterations of any kind since the counters were reset
   // lazily allocated scratch for the *_host conveniences
@@ -64,30 +66,26 @@ int dalloc(skyjo_vec *h, T **out, size_t count, bool zero = true) {
   return SKYJO_OK;
 }
 
-int prof_begin(skyjo_vec *h, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, hipStream_t s) {
+// Profiling: the kernel's own begin / end timestamps (the dispatch packet's completion signal, the same
+// source rocprofv3's kernel trace reads) are attached to a pair of events by hipExtLaunchKernelGGL.
+int prof_events(skyjo_vec *h, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, hipEvent_t *a, hipEvent_t *b) {
+  *a = *b = nullptr;
   if (!h->profile) return SKYJO_OK;
-  hipEvent_t a, b;
-  HIPCHK(hipEventCreate(&a));
-  HIPCHK(hipEventCreate(&b));
-  HIPCHK(hipEventRecord(a, s));
-  v.emplace_back(a, b);
-  return SKYJO_OK;
-}
-
-int prof_end(skyjo_vec *h, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, hipStream_t s) {
-  if (!h->profile) return SKYJO_OK;
-  HIPCHK(hipEventRecord(v.back().second, s));
+  HIPCHK(hipEventCreate(a));
+  HIPCHK(hipEventCreate(b));
+  v.emplace_back(*a, *b);
   return SKYJO_OK;
 }
 
 int launch_deal(skyjo_vec *h, hipStream_t s, bool all) {
   const int blocks = (h->P.B + SK_DEAL_SPAN - 1) / SK_DEAL_SPAN;
   int rc;
-  if ((rc = prof_begin(h, h->ev_deal, s))) return rc;
-  hipLaunchKernelGGL(k_deal, dim3(blocks), dim3(SK_TILE), h->lds_tile + 16384 + SK_DEAL_SPAN * sizeof(int32_t), s, h->P,
-                     all ? 1 : 0);
+  hipEvent_t e0, e1;
+  if ((rc = prof_events(h, h->ev_deal, &e0, &e1))) return rc;
+  hipExtLaunchKernelGGL(k_deal, dim3(blocks), dim3(SK_TILE),
+                        (uint32_t)(h->lds_tile + 16384 + SK_DEAL_SPAN * sizeof(int32_t)), s, e0, e1, 0, h->P,
+                        all ? 1 : 0);
   HIPCHK(hipGetLastError());
-  if ((rc = prof_end(h, h->ev_deal, s))) return rc;
   h->pending_deals = 0;
   return SKYJO_OK;
 }
@@ -96,18 +94,18 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
                 int iters, uint64_t policy_seed) {
   dim3 grid(h->P.tiles), block(SK_TILE);
   const bool ind = h->P.L.indirect != 0;
-#define LAUNCH(I, Pol)                                                                                          \
-  hipLaunchKernelGGL((k_step<I, Pol>), grid, block, h->lds_bytes, s, h->P, actions, rec, act_out, iters,       \
-                     policy_seed, h->iter)
-  int prc;
-  if ((prc = prof_begin(h, h->ev_step, s))) return prc;
+  int rc;
+  hipEvent_t e0, e1;
+  if ((rc = prof_events(h, h->ev_step, &e0, &e1))) return rc;
+#define LAUNCH(I, Pol)                                                                                              \
+  hipExtLaunchKernelGGL((k_step<I, Pol>), grid, block, (uint32_t)h->lds_bytes, s, e0, e1, 0, h->P, actions, rec,   \
+                        act_out, iters, policy_seed, h->iter)
   if (ind && policy) LAUNCH(true, true);
   else if (ind) LAUNCH(true, false);
   else if (policy) LAUNCH(false, true);
   else LAUNCH(false, false);
 #undef LAUNCH
   HIPCHK(hipGetLastError());
-  if ((prc = prof_end(h, h->ev_step, s))) return prc;
   h->iters_total += (uint64_t)iters;
   if (policy) h->iter += (uint64_t)iters;  // the policy's Philox counter counts rollout iterations only
   h->pending_deals++;
@@ -258,14 +256,18 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   hipStream_t s = (hipStream_t)stream;
   uint8_t *rec = (uint8_t *)records_out;
+  int since_deal = 0;
   for (int done = 0; done < iters;) {
     const int n = iters - done < kMaxRolloutChunk ? iters - done : kMaxRolloutChunk;
     int rc = launch_step(h, s, true, nullptr, rec, actions_out, n, policy_seed);
     if (rc) return rc;
-    if ((rc = launch_deal(h, s, false))) return rc;
+    done += n;
+    if (++since_deal >= h->rollout_deal_every || done >= iters) {
+      if ((rc = launch_deal(h, s, false))) return rc;
+      since_deal = 0;
+    }
     if (rec) rec += (size_t)n * h->P.B * h->P.L.rec_bytes;
     if (actions_out) actions_out += (size_t)n * h->P.B;
-    done += n;
   }
   return SKYJO_OK;
 }
@@ -483,6 +485,10 @@ int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
     case SKYJO_OPT_DEAL_INTERVAL:
       if (value < 1 || value > 64) return fail(SKYJO_E_INVALID, "deal interval must be in 1..64");
       h->deal_interval = (int)value;
+      return SKYJO_OK;
+    case SKYJO_OPT_ROLLOUT_DEAL_EVERY:
+      if (value < 1 || value > 16) return fail(SKYJO_E_INVALID, "rollout deal cadence must be in 1..16");
+      h->rollout_deal_every = (int)value;
       return SKYJO_OK;
     default:
       return fail(SKYJO_E_INVALID, "unknown option");

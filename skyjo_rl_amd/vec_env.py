@@ -220,12 +220,15 @@ class SkyjoVecEnv:
         """Collect-and-clear HIP-event timings of the kernels launched since the last call (bench roofline leg)."""
         sm, dm = C.c_double(), C.c_double()
         sl, dl = C.c_int64(), C.c_int64()
-        _lib.check(self._L.skyjo_vec_profile(self._h, int(bool(enable)), C.byref(sm), C.byref(sl), C.byref(dm),
+        _lib.check(self._L.skyjo_vec_profile(self._h, int(enable), C.byref(sm), C.byref(sl), C.byref(dm),
                                              C.byref(dl)))
         return dict(step_ms=sm.value, step_launches=sl.value, deal_ms=dm.value, deal_launches=dl.value)
 
     def set_deal_interval(self, n):
         _lib.check(self._L.skyjo_vec_set_option(self._h, 1, int(n)))
+
+    def set_rollout_deal_every(self, n):
+        _lib.check(self._L.skyjo_vec_set_option(self._h, 2, int(n)))
 
     def reset_counters(self):
         _lib.check(self._L.skyjo_vec_reset_counters(self._h, None))
