@@ -166,9 +166,13 @@ struct MtStream {
     }
   }
   __device__ __forceinline__ int close() const { return wrap(idx + used) | ((pend + wp - rp) << 16); }
-  __device__ __forceinline__ void refill() {  // regenerate elements gen .. gen+15 in place
+  // Regenerating elements gen .. gen+15 in place is split in two: refill_issue() starts the 33 loads,
+  // refill_finish() twists, tempers and stores.  The dealing kernel calls them a few shuffle iterations
+  // apart (service()), so the memory latency of a chunk hides behind the LDS work of the shuffle.
+  uint32_t o[17], x[16];
+  bool issued = false;
+  __device__ __forceinline__ void refill_issue() {
     const int c = gen;
-    uint32_t o[17], x[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) o[k] = mt[c + k];
     o[16] = mt[c + 16 == 624 ? 0 : c + 16];
@@ -177,6 +181,10 @@ struct MtStream {
       const int i = c + k;
       x[k] = mt[i < 227 ? i + 397 : i - 227];
     }
+    issued = true;
+  }
+  __device__ __forceinline__ void refill_finish() {
+    const int c = gen;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       uint32_t y = (o[k] & 0x80000000u) | (o[k + 1] & 0x7fffffffu);
@@ -187,19 +195,34 @@ struct MtStream {
     }
     wp += 16;
     gen = c + 16 == 624 ? 0 : c + 16;
+    issued = false;
   }
-  // called where the active lanes of the wavefront are converged: refill together when all have room
-  __device__ __forceinline__ void service() {
-    if (DEPTH >= 64 && __all(DEPTH - (wp - rp) >= 16)) {
+  __device__ __forceinline__ void refill() {
+    if (!issued) refill_issue();
+    refill_finish();
+  }
+  // Called every fourth draw of the dealing kernel's shuffle loop, where the active lanes are converged.
+  // When every lane has room for a chunk: finish the chunk whose loads were started at the previous call
+  // and start the next one.  A lane whose ring ran dry (fewer than `need` draws left) is served on its own.
+  // One code copy of issue / finish serves both cases (the loop runs once unless some lane is dry).
+  __device__ __forceinline__ void service(int need = 0) {
+    if (DEPTH < 64) return;
 #ifdef SK_STAMPS
-      Stamps &st = *stp;
-      STAMP(3);
-      refill();
-      STAMP(5);
-#else
-      refill();
+    Stamps &st = *stp;
+    STAMP(3);
 #endif
+#pragma unroll 1
+    for (int pass = 0; pass < 3; pass++) {
+      const bool room = DEPTH - (wp - rp) >= 16;
+      const bool dry = wp - rp < need;
+      const bool all_room = pass == 0 && __all(room);
+      if (!all_room && !__any(dry)) break;
+      if (issued && (dry || (all_room && __all(issued)))) refill_finish();
+      if (!issued && ((all_room && DEPTH - (wp - rp) >= 16) || wp - rp < need)) refill_issue();
     }
+#ifdef SK_STAMPS
+    STAMP(5);
+#endif
   }
   __device__ __forceinline__ void unget() {  // give back the draw returned by the last next()
     used--;
@@ -895,29 +918,85 @@ __device__ __forceinline__ void shuffle_lds(uint8_t *lp, int base, int n, Rng &r
   r.unget();  // the prefetched draw belongs to whoever consumes the stream next
 }
 
+// Dealing-kernel form: inside the loop every lane consumes exactly one draw per iteration, so the lanes
+// fetch their next four draws from the ring together (one LDS round trip per four draws) and the ring is
+// serviced for the whole wavefront at the same points.
+__device__ __forceinline__ void shuffle_lds(uint8_t *lp, int base, int n, MtStream<64> &r) {
+  int i = n - 1;
+  if (i < 1) return;
+  uint8_t *fp = r.fp;
+  uint32_t mask = 0xffffffffu >> __clz(i);
+  uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+  int ai = LB(base + i);  // a[i] is known one iteration ahead
+  for (int t = 0; i >= 1; t++) {
+    if ((t & 3) == 0) {  // wave-uniform
+      r.service(4);
+      q0 = MT_FIFO(r.rp & 63), q1 = MT_FIFO((r.rp + 1) & 63), q2 = MT_FIFO((r.rp + 2) & 63), q3 = MT_FIFO((r.rp + 3) & 63);
+    }
+    const uint32_t sel = (uint32_t)(t & 3);
+    const uint32_t v = (sel == 0 ? q0 : sel == 1 ? q1 : sel == 2 ? q2 : q3) & mask;
+    r.rp++, r.used++;
+    if (v <= (uint32_t)i) {
+      const int av = LB(base + (int)v);
+      LB(base + i) = (uint8_t)av, LB(base + (int)v) = (uint8_t)ai;
+      i--;
+      mask = 0xffffffffu >> __clz(i | 1);
+      ai = (int)v == i ? ai : LB(base + (i < 0 ? 0 : i));  // a[v] now holds the old a[i]
+    }
+  }
+}
+
 template <class Rng>
 __device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rng &r, uint32_t episode) {
   const int N = P.L.N, pb = P.L.off_pile, R = SK_NCARDS - 12 * N;
+  const int pw = pb >> 2, cw = P.L.off_cards >> 2;  // word indices (both regions are 4-byte aligned)
+  const int tmp = pb + R;                           // 12 free bytes behind the rest (R + 12 <= 150)
   for (int w = 0; w < P.L.chunks * 4; w++) LW(w) = 0;
-  // _new_drawpile: repeat(arange(-2, 13), 10) then shuffle (skyjo.py:76-82)
-  for (int i = 0; i < SK_NCARDS; i++) LB(pb + i) = (uint8_t)(int8_t)(-2 + i / 10);
-  shuffle_lds(lp, pb, SK_NCARDS, r);
-  // first 12N cards row-major to players 0..N-1 (skyjo.py:63-65)
-  for (int i = 0; i < 12 * N; i++) LB(P.L.off_cards + i) = LB(pb + i);
-  // the rest is shuffled again; all but its last card form the draw pile (skyjo.py:68-70,127-138)
-  for (int i = 0; i < R; i++) LB(pb + i) = LB(pb + 12 * N + i);
-  shuffle_lds(lp, pb, R, r);
-  // _reset_card_mask: two open cards per player = permutation(12)[:2] (skyjo.py:96-103)
-  const int tmp = pb + R;  // 12 free bytes behind the rest (R + 12 <= 150)
-  for (int p = 0; p < N; p++) {
-    for (int k = 0; k < 12; k++) LB(tmp + k) = (uint8_t)k, LB(P.L.off_vis + 12 * p + k) = SKYJO_HAND_NONE;
-    shuffle_lds(lp, tmp, 12, r);
-    int s0 = LB(tmp), s1 = LB(tmp + 1);
-    int c0 = LI(P.L.off_cards + 12 * p + s0), c1 = LI(P.L.off_cards + 12 * p + s1);
-    LB(P.L.off_vis + 12 * p + s0) = (uint8_t)c0, LB(P.L.off_vis + 12 * p + s1) = (uint8_t)c1;
-    LSH(P.L.off_sums + 2 * p) = (int16_t)(c0 + c1);
-    LB(P.L.off_hidden + p) = 10;
-    if (!P.L.indirect) LB(H_HIST + 2 + c0)++, LB(H_HIST + 2 + c1)++;
+  // _new_drawpile: repeat(arange(-2, 13), 10) then shuffle (skyjo.py:76-82); written four cards per word
+  for (int d = 0; d < (SK_NCARDS + 3) / 4; d++) {
+    uint32_t w = 0;
+    for (int j = 0; j < 4; j++) {
+      const int i = 4 * d + j;
+      w |= (i < SK_NCARDS ? (uint32_t)((-2 + i / 10) & 0xff) : 0u) << (8 * j);
+    }
+    LW(pw + d) = w;
+  }
+  // The N + 2 shuffles of a deal, in numpy's order, share ONE inlined copy of the
+  // shuffle loop (and of the MT19937 refill code in it): segment 0 = the deck, 1 = the rest,
+  // 2 + p = permutation(12) of player p.
+#pragma unroll 1
+  for (int seg = 0; seg < N + 2; seg++) {
+    int base = pb, n = SK_NCARDS;
+    if (seg == 1) {
+      // first 12N cards row-major to players 0..N-1 (skyjo.py:63-65)
+      for (int d = 0; d < 3 * N; d++) LW(cw + d) = LW(pw + d);
+      // the rest is shuffled again; all but its last card form the draw pile (skyjo.py:68-70,127-138).
+      // Word-wise move down by 3N words, 8 words at a time (reads of a batch precede its writes).
+      for (int d = 0; d < (R + 3) / 4; d += 8) {
+        uint32_t t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[k] = LW(pw + 3 * N + d + k);  // may run a few words past the pile: padding
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (d + k < (R + 3) / 4) LW(pw + d + k) = t[k];
+      }
+      n = R;
+    } else if (seg >= 2) {
+      // _reset_card_mask: two open cards per player = permutation(12)[:2] (skyjo.py:96-103)
+      const int p = seg - 2;
+      for (int k = 0; k < 12; k++) LB(tmp + k) = (uint8_t)k, LB(P.L.off_vis + 12 * p + k) = SKYJO_HAND_NONE;
+      base = tmp, n = 12;
+    }
+    shuffle_lds(lp, base, n, r);
+    if (seg >= 2) {
+      const int p = seg - 2;
+      int s0 = LB(tmp), s1 = LB(tmp + 1);
+      int c0 = LI(P.L.off_cards + 12 * p + s0), c1 = LI(P.L.off_cards + 12 * p + s1);
+      LB(P.L.off_vis + 12 * p + s0) = (uint8_t)c0, LB(P.L.off_vis + 12 * p + s1) = (uint8_t)c1;
+      LSH(P.L.off_sums + 2 * p) = (int16_t)(c0 + c1);
+      LB(P.L.off_hidden + p) = 10;
+      if (!P.L.indirect) LB(H_HIST + 2 + c0)++, LB(H_HIST + 2 + c1)++;
+    }
   }
   for (int k = R; k < SK_NCARDS; k++) LB(pb + k) = 0;
   const int last = LI(pb + R - 1);
