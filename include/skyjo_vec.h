@@ -185,12 +185,10 @@ int skyjo_vec_profile(skyjo_vec *h, int enable, double *step_ms, int64_t *step_l
  * the dealing kernel, summed over wavefronts, cleared on read.  The shipped build returns zeros. */
 int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
 
-/* Tunables.  SKYJO_OPT_DEAL_INTERVAL: skyjo_vec_step launches between two runs of the dealing kernel
- * (1..64, default 1); a finished game whose next deal is not ready yet deals in place (slow path). */
+/* Tunables.  SKYJO_OPT_DEAL_INTERVAL: lockstep iterations (steps or rollout iterations) between two runs of the
+ * dealing kernel (1..1024, default 64).  Every game owns a bank of two pre-dealt episodes and the dealing kernel
+ * adds at most one per game and run; a finished game whose bank is empty deals in place (slow path, same result). */
 #define SKYJO_OPT_DEAL_INTERVAL 1
-/* SKYJO_OPT_ROLLOUT_DEAL_EVERY: step-kernel launches (16 iterations each) between two dealing-kernel launches
- * inside skyjo_vec_rollout (1..16, default 1). */
-#define SKYJO_OPT_ROLLOUT_DEAL_EVERY 2
 int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value);
 
 /* host-pointer conveniences for small batches (single-game AEC view): synchronous */

@@ -28,7 +28,9 @@ int fail(int code, const std::string &msg) {
       return fail(SKYJO_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));             \
   } while (0)
 
-constexpr int kMaxRolloutChunk = 16;  // iterations per launch: shorter than any episode, so a game
+constexpr int kMaxRolloutChunk = 16;
+constexpr int kDealEveryIters = 64;  // default: lockstep iterations between two k_deal launches (the bank is 2 deep
+                                     // and no episode of two or more players is shorter than 41 steps)  // iterations per launch: shorter than any episode, so a game
                                       // never needs two fresh deals inside one launch
 
 }  // namespace
@@ -39,9 +41,8 @@ struct skyjo_vec {
   size_t G = 0;           // tiles * 64
   size_t lds_bytes = 0, lds_tile = 0;
   bool seeded = false;
-  int pending_deals = 0;  // step launches since the dealing kernel last ran
-  int deal_interval = 1;
-  int rollout_deal_every = 1;  // k_step launches between two k_deal launches inside skyjo_vec_rollout
+  int pending_iters = 0;  // lockstep iterations since the dealing kernel last ran
+  int deal_every_iters = kDealEveryIters;  // k_step launches between two k_deal launches inside skyjo_vec_rollout
   uint64_t iter = 0;        // rollout iterations (the policy's Philox counter)
   uint64_t iters_total = 0; // lockstep iterations of any kind since the counters were reset
   // lazily allocated scratch for the *_host conveniences
@@ -77,16 +78,15 @@ int prof_events(skyjo_vec *h, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v,
   return SKYJO_OK;
 }
 
-int launch_deal(skyjo_vec *h, hipStream_t s, bool all) {
+int launch_deal(skyjo_vec *h, hipStream_t s) {
   const int blocks = (h->P.B + SK_DEAL_SPAN - 1) / SK_DEAL_SPAN;
   int rc;
   hipEvent_t e0, e1;
   if ((rc = prof_events(h, h->ev_deal, &e0, &e1))) return rc;
   hipExtLaunchKernelGGL(k_deal, dim3(blocks), dim3(SK_TILE),
-                        (uint32_t)(h->lds_tile + 16384 + SK_DEAL_SPAN * sizeof(int32_t)), s, e0, e1, 0, h->P,
-                        all ? 1 : 0);
+                        (uint32_t)(h->lds_tile + 16384 + SK_DEAL_SPAN * sizeof(int32_t)), s, e0, e1, 0, h->P);
   HIPCHK(hipGetLastError());
-  h->pending_deals = 0;
+  h->pending_iters = 0;
   return SKYJO_OK;
 }
 
@@ -108,7 +108,7 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
   HIPCHK(hipGetLastError());
   h->iters_total += (uint64_t)iters;
   if (policy) h->iter += (uint64_t)iters;  // the policy's Philox counter counts rollout iterations only
-  h->pending_deals++;
+  h->pending_iters += iters;
   return SKYJO_OK;
 }
 
@@ -165,9 +165,9 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   const size_t rec16 = (size_t)P.tiles * P.L.chunks * SK_TILE;
   int rc = SKYJO_OK;
   const size_t N = (size_t)cfg->num_players;
-  if ((rc = dalloc(h, &P.state, rec16)) || (rc = dalloc(h, &P.spare, rec16)) ||
-      (rc = dalloc(h, &P.spare_ready, h->G)) ||
-      (rc = dalloc(h, &P.mt_idx, 2 * h->G)) || (rc = dalloc(h, &P.seeds, h->G)) ||
+  if ((rc = dalloc(h, &P.state, rec16)) || (rc = dalloc(h, &P.spare, 2 * rec16)) ||
+      (rc = dalloc(h, &P.spare_ready, 2 * h->G)) || (rc = dalloc(h, &P.bank_head, h->G)) ||
+      (rc = dalloc(h, &P.mt_idx, 3 * h->G)) || (rc = dalloc(h, &P.seeds, h->G)) ||
       (rc = dalloc(h, &P.deals_consumed, h->G)) || (rc = dalloc(h, &P.rewards, h->G * N)) ||
       (rc = dalloc(h, &P.scores, h->G * N)) || (rc = dalloc(h, &P.done, h->G)) ||
       (rc = dalloc(h, &P.acc_tile, (size_t)P.tiles * 2 * SKYJO_MAX_PLAYERS)) ||
@@ -175,7 +175,7 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     skyjo_vec_destroy(h);
     return rc;
   }
-  if (cfg->rng_mode == SKYJO_RNG_MT19937 && (rc = dalloc(h, &P.mt, 2 * h->G * 624, false))) {
+  if (cfg->rng_mode == SKYJO_RNG_MT19937 && (rc = dalloc(h, &P.mt, 3 * h->G * 624, false))) {
     skyjo_vec_destroy(h);
     return rc;
   }
@@ -213,8 +213,8 @@ int skyjo_vec_seed(skyjo_vec *h, const uint64_t *seeds_host, uint64_t base_seed,
                      h->P.B);
   HIPCHK(hipGetLastError());
   int rc;
-  // set_seed deals immediately (skyjo.py:88): deal #0 becomes the live game, deal #1 is pre-dealt
-  if ((rc = launch_deal(h, s, true))) return rc;
+  // set_seed deals immediately (skyjo.py:88): deal #0 becomes the live game, deals #1 and #2 fill the bank
+  if ((rc = launch_deal(h, s))) return rc;
   h->seeded = true;
   if ((rc = skyjo_vec_reset(h, nullptr, nullptr, stream))) return rc;
   if (d_seeds) {
@@ -230,14 +230,15 @@ int skyjo_vec_reset(skyjo_vec *h, const uint8_t *mask, void *records_out, void *
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (h->pending_deals > 0 && (rc = launch_deal(h, s, false))) return rc;  // make every next deal available
+  if (h->pending_iters > 0 && (rc = launch_deal(h, s))) return rc;  // make a next deal available where possible
   dim3 grid(h->P.tiles), block(SK_TILE);
   if (h->P.L.indirect)
     hipLaunchKernelGGL((k_reset<true>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out);
   else
     hipLaunchKernelGGL((k_reset<false>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out);
   HIPCHK(hipGetLastError());
-  return launch_deal(h, s, false);
+  if ((rc = launch_deal(h, s))) return rc;  // one deal per game and launch: two launches refill the bank
+  return launch_deal(h, s);
 }
 
 int skyjo_vec_step(skyjo_vec *h, const int32_t *actions, void *records_out, void *stream) {
@@ -246,7 +247,7 @@ int skyjo_vec_step(skyjo_vec *h, const int32_t *actions, void *records_out, void
   hipStream_t s = (hipStream_t)stream;
   int rc = launch_step(h, s, false, actions, (uint8_t *)records_out, nullptr, 1, 0);
   if (rc) return rc;
-  if (h->pending_deals >= h->deal_interval) return launch_deal(h, s, false);
+  if (h->pending_iters >= h->deal_every_iters) return launch_deal(h, s);
   return SKYJO_OK;
 }
 
@@ -256,16 +257,12 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   hipStream_t s = (hipStream_t)stream;
   uint8_t *rec = (uint8_t *)records_out;
-  int since_deal = 0;
   for (int done = 0; done < iters;) {
     const int n = iters - done < kMaxRolloutChunk ? iters - done : kMaxRolloutChunk;
     int rc = launch_step(h, s, true, nullptr, rec, actions_out, n, policy_seed);
     if (rc) return rc;
     done += n;
-    if (++since_deal >= h->rollout_deal_every || done >= iters) {
-      if ((rc = launch_deal(h, s, false))) return rc;
-      since_deal = 0;
-    }
+    if (h->pending_iters >= h->deal_every_iters && (rc = launch_deal(h, s))) return rc;
     if (rec) rec += (size_t)n * h->P.B * h->P.L.rec_bytes;
     if (actions_out) actions_out += (size_t)n * h->P.B;
   }
@@ -419,6 +416,8 @@ int skyjo_vec_set_state(skyjo_vec *h, int32_t game, const skyjo_game_state *in, 
   r[H_MINHID] = (uint8_t)mh;
   r[H_TOP] = in->n_disc ? (uint8_t)in->discard_pile[in->n_disc - 1] : (uint8_t)(int8_t)-3;
   r[H_HAND] = (uint8_t)in->hand_card;
+  HIPCHK(hipMemcpyAsync(&r[H_BANK], h->P.bank_head + game, 1, hipMemcpyDeviceToHost, s));  // keep the bank pointer
+  HIPCHK(hipStreamSynchronize(s));
   uint8_t *dst = (uint8_t *)(h->P.state + ((size_t)(game / SK_TILE) * L.chunks) * SK_TILE + game % SK_TILE);
   HIPCHK(hipMemcpy2DAsync(dst, SK_TILE * 16, r.data(), 16, 16, L.chunks, hipMemcpyHostToDevice, s));
   uint8_t dn = (r[H_FLAGS] & F_DONE) ? 1 : 0;
@@ -438,10 +437,10 @@ int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream)
   if (h->P.rng_mode != SKYJO_RNG_MT19937) return fail(SKYJO_E_STATE, "seed_raw needs the MT19937 mode");
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (h->pending_deals > 0 && (rc = launch_deal(h, s, false))) return rc;
+  if (h->pending_iters > 0 && (rc = launch_deal(h, s))) return rc;
   hipLaunchKernelGGL(k_seed_raw, dim3(1), dim3(64), 0, s, h->P, game, value);
   HIPCHK(hipGetLastError());
-  return launch_deal(h, s, false);
+  return launch_deal(h, s);
 }
 
 int skyjo_vec_profile(skyjo_vec *h, int enable, double *step_ms, int64_t *step_launches, double *deal_ms,
@@ -483,12 +482,8 @@ int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
   switch (option) {
     case SKYJO_OPT_DEAL_INTERVAL:
-      if (value < 1 || value > 64) return fail(SKYJO_E_INVALID, "deal interval must be in 1..64");
-      h->deal_interval = (int)value;
-      return SKYJO_OK;
-    case SKYJO_OPT_ROLLOUT_DEAL_EVERY:
-      if (value < 1 || value > 16) return fail(SKYJO_E_INVALID, "rollout deal cadence must be in 1..16");
-      h->rollout_deal_every = (int)value;
+      if (value < 1 || value > 1024) return fail(SKYJO_E_INVALID, "deal interval must be in 1..1024");
+      h->deal_every_iters = (int)value;
       return SKYJO_OK;
     default:
       return fail(SKYJO_E_INVALID, "unknown option");

@@ -28,10 +28,11 @@ struct SkParams {
   double score_penalty, mean_reward, reward_refunded, illegal_reward;
   uint64_t game_id0;
   uint4 *state;             // [tiles][chunks][64] live games
-  uint4 *spare;             // [tiles][chunks][64] pre-dealt next episode of every game
-  uint8_t *spare_ready;     // [tiles*64]
-  uint32_t *mt;             // [2][tiles*64][624]: [0] numpy-legacy MT19937 state, [1] undo log of the pre-deal
-  int32_t *mt_idx;          // [2][tiles*64]: [0] stream position (idx | ahead << 16), [1] position before the pre-deal
+  uint4 *spare;             // [2][tiles][chunks][64] the two pre-dealt next episodes of every game (a 2-deep bank)
+  uint8_t *spare_ready;     // [2][tiles*64]
+  uint8_t *bank_head;       // [tiles*64] slot that is taken next; slot head^1 holds the episode after it
+  uint32_t *mt;             // [3][tiles*64][624]: [0] numpy-legacy MT19937 state, [1 + slot] undo log of that slot's deal
+  int32_t *mt_idx;          // [3][tiles*64]: [0] stream position (idx | ahead << 16), [1 + slot] position before its deal
   uint64_t *seeds;          // [tiles*64] value given to set_seed
   uint32_t *deals_consumed; // [tiles*64]
   double *rewards;          // [tiles*64][N]
@@ -333,16 +334,20 @@ __device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *l
     const size_t G = (size_t)P.tiles * SK_TILE;
     uint32_t *mt = P.mt + (size_t)g * 624;
     int packed = P.mt_idx[g];
-    if (P.spare_ready[g]) {
-      // The pre-dealt next episode consumed the stream beyond this point (numpy draws the reshuffle first):
-      // roll the state back with the undo log, k_deal deals again afterwards.
-      const uint32_t *undo = P.mt + (G + g) * 624;
-      const int snap = P.mt_idx[G + g];
-      int from = (snap & 0xffff) + (snap >> 16), to = (packed & 0xffff) + (packed >> 16);
-      from = from >= 624 ? from - 624 : from, to = to >= 624 ? to - 624 : to;
-      for (int i = from; i != to; i = i + 1 == 624 ? 0 : i + 1) mt[i] = undo[i];
-      packed = snap;
-      P.spare_ready[g] = 0;
+    // The pre-dealt episodes consumed the stream beyond this point (numpy draws the reshuffle first): roll the
+    // state back with their undo logs, newest deal first; k_deal deals them again afterwards.
+    const int head = LB(H_BANK);
+    for (int k = 1; k >= 0; k--) {
+      const int slot = head ^ k;
+      if (P.spare_ready[(size_t)slot * G + g]) {
+        const uint32_t *undo = P.mt + ((size_t)(1 + slot) * G + g) * 624;
+        const int snap = P.mt_idx[(size_t)(1 + slot) * G + g];
+        int from = (snap & 0xffff) + (snap >> 16), to = (packed & 0xffff) + (packed >> 16);
+        from = from >= 624 ? from - 624 : from, to = to >= 624 ? to - 624 : to;
+        for (int i = from; i != to; i = i + 1 == 624 ? 0 : i + 1) mt[i] = undo[i];
+        packed = snap;
+        P.spare_ready[(size_t)slot * G + g] = 0;
+      }
     }
     MtStream<16> r;
     r.open(mt, packed, fp);
@@ -682,10 +687,12 @@ __device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, cons
 // Take the pre-dealt next episode (SkyjoGame.reset, skyjo.py:52-74; the dealing itself is k_deal).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, int tile, int lane, int g) {
-  const uint4 *s = P.spare + (size_t)tile * P.L.chunks * SK_TILE + lane;
+  const size_t G = (size_t)P.tiles * SK_TILE;
+  const int head = LB(H_BANK) & 1;
+  const uint4 *s = P.spare + ((size_t)head * P.tiles + tile) * P.L.chunks * SK_TILE + lane;
   const int n = P.L.chunks;
   // flags and the first 9 chunks are requested together (the record is read even if it turns out not to be ready)
-  const uint8_t ready = P.spare_ready[g];
+  const uint8_t ready = P.spare_ready[(size_t)head * G + g];
   const uint32_t dc = P.deals_consumed[g];
   uint4 v[9];
 #pragma unroll
@@ -706,7 +713,9 @@ __device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, in
         LW(w + 0) = v[k].x, LW(w + 1) = v[k].y, LW(w + 2) = v[k].z, LW(w + 3) = v[k].w;
       }
   }
-  P.spare_ready[g] = 0;  // k_deal finds the empty slots with a ballot scan
+  P.spare_ready[(size_t)head * G + g] = 0;  // k_deal finds the empty slots with a ballot scan
+  P.bank_head[g] = (uint8_t)(head ^ 1);
+  LB(H_BANK) = (uint8_t)(head ^ 1);
   P.deals_consumed[g] = dc + 1;
   P.done[g] = 0;
   return true;
@@ -834,13 +843,11 @@ __global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *ma
   uint8_t *fp = lp + P.L.chunks * 1024;
   if (g >= P.B) return;
   const bool want = !mask || mask[g];
-  bool took = false;
+  tile_load(P, P.state, tile, lane, lp);  // (the bank pointer of the game lives in its record)
   if (want) {
-    took = true;
     if (!consume_spare(P, lp, tile, lane, g)) deal_inline(P, lp, fp, g);
     LB(H_STATUS) = SKYJO_ST_RESET;
   }
-  if (!took) tile_load(P, P.state, tile, lane, lp);
   HdrRegs h;
   HDR_LOAD(h);
   if (rec_out) emit_record<INDIRECT>(P, lp, h, LB(H_PLAYER), rec_out + (size_t)g * P.L.rec_bytes);
@@ -860,7 +867,8 @@ __global__ void k_seed(SkParams P, const uint64_t *seeds, uint64_t base, int fir
   const size_t G = (size_t)P.tiles * SK_TILE;
   P.seeds[g] = value;
   P.deals_consumed[g] = 0;
-  P.spare_ready[g] = 0;
+  P.spare_ready[g] = 0, P.spare_ready[G + g] = 0;
+  P.bank_head[g] = 0;
   if (P.rng_mode == SKYJO_RNG_MT19937) {
     uint32_t *mt = P.mt + (size_t)g * 624;
     uint32_t x = (uint32_t)(value + 1);
@@ -870,7 +878,6 @@ __global__ void k_seed(SkParams P, const uint64_t *seeds, uint64_t base, int fir
       mt[k] = x;
     }
     P.mt_idx[g] = 0;
-    P.mt_idx[G + g] = 0;
   }
 }
 
@@ -885,7 +892,8 @@ __global__ void k_seed_raw(SkParams P, int g, uint32_t value) {
     mt[k] = x;
   }
   P.mt_idx[g] = 0;
-  P.spare_ready[g] = 0;  // whatever was pre-dealt belongs to the old stream
+  const size_t G = (size_t)P.tiles * SK_TILE;
+  P.spare_ready[g] = 0, P.spare_ready[G + g] = 0;  // whatever was pre-dealt belongs to the old stream
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1018,6 +1026,7 @@ __device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rn
 
 __device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g) {
   const uint32_t ep = P.deals_consumed[g];
+  const uint8_t bank = LB(H_BANK);  // the bank is empty here; its head pointer survives the new record
   if (P.rng_mode == SKYJO_RNG_MT19937) {
     MtStream<16> r;
     r.open(P.mt + (size_t)g * 624, P.mt_idx[g], fp);
@@ -1028,6 +1037,7 @@ __device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint
     r.open(P.seeds[g] + 1, ep, 0u, 0u);
     deal_into_lds(P, lp, r, ep);
   }
+  LB(H_BANK) = bank;
   P.deals_consumed[g] = ep + 1;
   P.done[g] = 0;
 }
@@ -1035,8 +1045,8 @@ __device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint
 // Each workgroup (one wavefront) owns SK_DEAL_SPAN consecutive games, finds the ones whose spare
 // record is empty with a wavefront ballot + prefix popcount, compacts their ids into LDS and then
 // deals them one lane per game, so the long serial shuffles run on densely populated waves.
-#define SK_DEAL_SPAN 256
-__global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int all) {
+#define SK_DEAL_SPAN 64
+__global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P) {
   extern __shared__ uint32_t lds_raw[];
   const int lane = threadIdx.x;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
@@ -1050,7 +1060,11 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int all) {
   int count = 0;
   for (int base = 0; base < SK_DEAL_SPAN; base += SK_TILE) {
     const int g = g0 + base + lane;
-    const bool need = g < P.B && (all || !P.spare_ready[g]);
+    bool need = false;
+    if (g < P.B) {  // at most one deal per game and launch: the older empty slot of its 2-deep bank
+      const int head = P.bank_head[g] & 1;
+      need = !P.spare_ready[(size_t)head * G + g] || !P.spare_ready[(size_t)(head ^ 1) * G + g];
+    }
     const unsigned long long b = __ballot(need);
     if (need) work[count + __popcll(b & ((1ull << lane) - 1ull))] = g;
     count += __popcll(b);
@@ -1060,45 +1074,48 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int all) {
   for (int base = 0; base < count; base += SK_TILE) {
     const bool act = base + lane < count;
     const int g = act ? work[base + lane] : 0;
+    const int head = act ? (P.bank_head[g] & 1) : 0;
+    const bool head_ready = act && P.spare_ready[(size_t)head * G + g];
+    const int slot = head_ready ? head ^ 1 : head;  // slots fill in stream order: head first
+    const uint32_t ep = act ? P.deals_consumed[g] + (head_ready ? 1u : 0u) : 0u;
     bool mt_overrun = false;
     if (P.rng_mode == SKYJO_RNG_MT19937) {
-      // The stream advances in place; the old value of every regenerated element goes to the undo log so
-      // that a mid-game reshuffle of the live episode (which numpy would have drawn BEFORE this deal) can
-      // roll the stream back and have this deal redone (reshuffle_dispatch).
+      // The stream advances in place; the old value of every regenerated element goes to the slot's undo log
+      // so that a mid-game reshuffle of the live episode (which numpy would have drawn BEFORE this deal) can
+      // roll the stream back and have the deal redone (reshuffle_dispatch).
       if (act) {
+        uint32_t *mt = P.mt + (size_t)g * 624, *undo = P.mt + ((size_t)(1 + slot) * G + g) * 624;
         const int packed = P.mt_idx[g];
-        P.mt_idx[G + g] = packed;
+        P.mt_idx[(size_t)(1 + slot) * G + g] = packed;
         MtStream<64> r;
-        r.open(P.mt + (size_t)g * 624, packed, fp, P.mt + (G + g) * 624);
+        r.open(mt, packed, fp, undo);
         r.stp = &st;
         STAMP(2);
-        deal_into_lds(P, lp, r, P.deals_consumed[g]);
+        deal_into_lds(P, lp, r, ep);
         P.mt_idx[g] = r.close();
-        mt_overrun = r.wp - (packed >> 16) > 624 - 64;  // undo log wrapped: give this speculation up
+        const int generated = r.wp - (packed >> 16);
+        mt_overrun = generated > 624 - 64;  // the undo log is about to wrap: give this speculation up
         if (mt_overrun) {
-          uint32_t *mt = P.mt + (size_t)g * 624;
-          const uint32_t *undo = P.mt + (G + g) * 624;
           int i = (packed & 0xffff) + (packed >> 16);
           i = i >= 624 ? i - 624 : i;
-          for (int k = 0; k < 624; k++, i = i + 1 == 624 ? 0 : i + 1) mt[i] = undo[i];  // oldest values win
+          for (int k = 0; k < generated; k++, i = i + 1 == 624 ? 0 : i + 1) mt[i] = undo[i];
           P.mt_idx[g] = packed;
         }
         STAMP(3);
       }
     } else if (act) {
       PhiloxStream r;
-      const uint32_t ep = P.deals_consumed[g];
       r.open(P.seeds[g] + 1, ep, 0u, 0u);
       deal_into_lds(P, lp, r, ep);
     }
     if (act && !mt_overrun) {  // (an overrun game deals in place when its episode ends: deal_inline)
-      tile_store(P, P.spare, g / SK_TILE, g % SK_TILE, lp);
-      P.spare_ready[g] = 1;
+      tile_store(P, P.spare + (size_t)slot * P.tiles * P.L.chunks * SK_TILE, g / SK_TILE, g % SK_TILE, lp);
+      P.spare_ready[(size_t)slot * G + g] = 1;
       STAMP(4);
     }
   }
 #ifdef SK_STAMPS
-  if (lane == 0)
+  if (lane == 0 && tile < P.tiles)
     for (int k = 0; k < 8; k++) P.stamps[(size_t)(P.tiles + tile) * 8 + k] += st.acc[k];
 #endif
 }

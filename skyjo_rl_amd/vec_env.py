@@ -227,8 +227,6 @@ class SkyjoVecEnv:
     def set_deal_interval(self, n):
         _lib.check(self._L.skyjo_vec_set_option(self._h, 1, int(n)))
 
-    def set_rollout_deal_every(self, n):
-        _lib.check(self._L.skyjo_vec_set_option(self._h, 2, int(n)))
 
     def reset_counters(self):
         _lib.check(self._L.skyjo_vec_reset_counters(self._h, None))
