@@ -97,13 +97,21 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
   int rc;
   hipEvent_t e0, e1;
   if ((rc = prof_events(h, h->ev_step, &e0, &e1))) return rc;
-#define LAUNCH(I, Pol)                                                                                              \
-  hipExtLaunchKernelGGL((k_step<I, Pol>), grid, block, (uint32_t)h->lds_bytes, s, e0, e1, 0, h->P, actions, rec,   \
-                        act_out, iters, policy_seed, h->iter)
-  if (ind && policy) LAUNCH(true, true);
-  else if (ind) LAUNCH(true, false);
-  else if (policy) LAUNCH(false, true);
-  else LAUNCH(false, false);
+#define LAUNCH3(I, Pol, NP)                                                                                       \
+  hipExtLaunchKernelGGL((k_step<I, Pol, NP>), grid, block, (uint32_t)h->lds_bytes, s, e0, e1, 0, h->P, actions,   \
+                        rec, act_out, iters, policy_seed, h->iter)
+#define LAUNCH(I, Pol)                                \
+  switch (h->P.L.N) {                                 \
+    case 2: LAUNCH3(I, Pol, 2); break;                \
+    case 3: LAUNCH3(I, Pol, 3); break;                \
+    case 4: LAUNCH3(I, Pol, 4); break;                \
+    default: LAUNCH3(I, Pol, 0); break;               \
+  }
+  if (ind && policy) LAUNCH(true, true)
+  else if (ind) LAUNCH(true, false)
+  else if (policy) LAUNCH(false, true)
+  else LAUNCH(false, false)
+#undef LAUNCH3
 #undef LAUNCH
   HIPCHK(hipGetLastError());
   h->iters_total += (uint64_t)iters;

@@ -730,9 +730,13 @@ __device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint
 // k_step: `iters` lockstep iterations over all tiles.  POLICY=false: one iteration with the
 // caller's actions (SimpleSkyjoEnv.step); POLICY=true: on-device random admissible policy.
 // ------------------------------------------------------------------------------------------
-template <bool INDIRECT, bool POLICY>
-__global__ __launch_bounds__(SK_TILE) void k_step(SkParams P, const int32_t *actions, uint8_t *rec_out,
+// NP > 0 fixes the player count at compile time (2, 3 and 4 are instantiated): every record offset becomes
+// an immediate and the per-player loops unroll; NP == 0 is the generic kernel for any 1..12 players.
+template <bool INDIRECT, bool POLICY, int NP>
+__global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *actions, uint8_t *rec_out,
                                                   int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0) {
+  SkParams P = Pin;
+  if (NP > 0) P.L = sk_make_layout(NP, INDIRECT ? 1 : 0);  // same values as the host computed, now constants
   extern __shared__ uint32_t lds_raw[];
   const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 4;

@@ -46,7 +46,12 @@ struct SkLayout {
   int32_t state_bytes, chunks;  // chunks = state_bytes / 16
 };
 
-static inline SkLayout sk_make_layout(int N, int indirect) {
+#ifdef __HIPCC__
+#define SK_HD __host__ __device__
+#else
+#define SK_HD
+#endif
+SK_HD static inline SkLayout sk_make_layout(int N, int indirect) {
   SkLayout L;
   L.N = N;
   L.indirect = indirect ? 1 : 0;

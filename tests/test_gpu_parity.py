@@ -203,6 +203,41 @@ def test_rollout_vs_oracle(N, ind, rng_mode, B):
     eng.close()
 
 
+@pytest.mark.parametrize("interval", [1, 16, 1000])
+@pytest.mark.parametrize("N,rng_mode", [(2, 0), (12, 0), (1, 1)])
+def test_deal_cadence_does_not_change_results(N, rng_mode, interval):
+    """However rarely the dealing kernel runs (bank of pre-dealt episodes full, partly filled or empty - then the
+    lane deals in place), and however often a mid-game reshuffle rolls the stream back (N=12), every step equals
+    the oracle's."""
+    import torch
+
+    B = 192
+    cfg = dict(num_players=N, score_penalty=2.0, observe_other_player_indirect=True, mean_reward=1.0,
+               reward_refunded=0.001, rng_mode=rng_mode, auto_reset=True)
+    eng = _engine(B, **cfg)
+    eng.set_deal_interval(interval)
+    ora = _oracle_vec(num_envs=B, **cfg)
+    eng.seed(None, 31)
+    ora.seed(None, 31)
+    K = 48
+    for r in range(10):
+        rec = eng.new_records(K)
+        act = torch.empty((K, B), dtype=torch.int32, device="cuda")
+        eng.rollout(K, policy_seed=9, records=rec, actions=act)
+        oact = ora.rollout(K, 9, record_actions=True)
+        np.testing.assert_array_equal(act.cpu().numpy(), oact, err_msg=f"round {r}")
+        last = eng.split(rec[K - 1])
+        obs, mask, agent, phase = ora.observe()
+        np.testing.assert_array_equal(last.observations.cpu().numpy(), obs)
+        np.testing.assert_array_equal(last.action_mask.cpu().numpy(), mask)
+    c, oc = eng.counters(), ora.counters()
+    for k in ("steps", "episodes", "resets", "sum_len"):
+        assert c[k] == oc[k], (k, c[k], oc[k])
+    if interval == 1000 and N <= 2:
+        assert c["waits"] > 0  # the bank ran empty: episodes were dealt on the in-kernel slow path
+    eng.close()
+
+
 def test_headline_size_properties():
     """BASELINE config 3 (65 536 three-player games): size-independent invariants + an oracle-checked subset."""
     import torch
