@@ -160,8 +160,10 @@ struct MtStream {
     const int ahead = packed >> 16;
     gen = wrap(idx + ahead), rp = 0, wp = 0, used = 0, pend = 0;
     if (DEPTH >= 64) {
-      for (int j = 0; j < ahead; j++) MT_FIFO(j) = mt_temper(mt[wrap(idx + j)]);
-      wp = ahead;
+      // the stream position idx + ahead is a multiple of 16: start the ring so that wp stays one too
+      rp = (16 - (ahead & 15)) & 15;
+      for (int j = 0; j < ahead; j++) MT_FIFO(rp + j) = mt_temper(mt[wrap(idx + j)]);
+      wp = rp + ahead;
     } else {
       pend = ahead;
     }
@@ -173,27 +175,43 @@ struct MtStream {
   uint32_t o[17], x[16];
   bool issued = false;
   __device__ __forceinline__ void refill_issue() {
-    const int c = gen;
+    const int c = gen;  // multiple of 16, so &mt[c] is 64-byte aligned
+    const uint4 *po = (const uint4 *)(mt + c);
 #pragma unroll
-    for (int k = 0; k < 16; k++) o[k] = mt[c + k];
+    for (int k = 0; k < 4; k++) {
+      const uint4 q = po[k];
+      o[4 * k] = q.x, o[4 * k + 1] = q.y, o[4 * k + 2] = q.z, o[4 * k + 3] = q.w;
+    }
     o[16] = mt[c + 16 == 624 ? 0 : c + 16];
+    if (c != 224) {  // elements i + 397 (mod 624) are contiguous for the whole chunk: four 16-byte loads
+      const uint32_t *px = mt + (c < 224 ? c + 397 : c - 227);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const int i = c + k;
-      x[k] = mt[i < 227 ? i + 397 : i - 227];
+      for (int k = 0; k < 16; k++) x[k] = px[k];
+    } else {  // the one chunk that straddles the wrap (i = 224..226 -> 621..623, i = 227.. -> 0..)
+#pragma unroll
+      for (int k = 0; k < 16; k++) x[k] = mt[k < 3 ? 621 + k : k - 3];
     }
     issued = true;
   }
   __device__ __forceinline__ void refill_finish() {
     const int c = gen;
+    uint32_t v[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       uint32_t y = (o[k] & 0x80000000u) | (o[k + 1] & 0x7fffffffu);
-      uint32_t v = x[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-      if (DEPTH >= 64) undo[c + k] = o[k];
-      mt[c + k] = v;
-      MT_FIFO((wp + k) & (DEPTH - 1)) = mt_temper(v);
+      v[k] = x[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
     }
+    uint4 *pm = (uint4 *)(mt + c);
+#pragma unroll
+    for (int k = 0; k < 4; k++) pm[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    if (DEPTH >= 64) {
+      uint4 *pu = (uint4 *)(undo + c);
+#pragma unroll
+      for (int k = 0; k < 4; k++) pu[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    }
+    const int w0 = wp & (DEPTH - 1);  // wp is a multiple of 16 whenever a chunk is appended
+#pragma unroll
+    for (int k = 0; k < 16; k++) MT_FIFO(w0 + k) = mt_temper(v[k]);
     wp += 16;
     gen = c + 16 == 624 ? 0 : c + 16;
     issued = false;
@@ -1097,7 +1115,7 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P) {
         STAMP(2);
         deal_into_lds(P, lp, r, ep);
         P.mt_idx[g] = r.close();
-        const int generated = r.wp - (packed >> 16);
+        const int generated = (r.wp & ~15) - (((16 - ((packed >> 16) & 15)) & 15) + (packed >> 16));
         mt_overrun = generated > 624 - 64;  // the undo log is about to wrap: give this speculation up
         if (mt_overrun) {
           int i = (packed & 0xffff) + (packed >> 16);
