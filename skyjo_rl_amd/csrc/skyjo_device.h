@@ -184,9 +184,13 @@ struct MtStream {
     }
     o[16] = mt[c + 16 == 624 ? 0 : c + 16];
     if (c != 224) {  // elements i + 397 (mod 624) are contiguous for the whole chunk: four 16-byte loads
-      const uint32_t *px = mt + (c < 224 ? c + 397 : c - 227);
+      typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // only dword-aligned
+      const u32x4_a4 *px = (const u32x4_a4 *)(mt + (c < 224 ? c + 397 : c - 227));
 #pragma unroll
-      for (int k = 0; k < 16; k++) x[k] = px[k];
+      for (int k = 0; k < 4; k++) {
+        const u32x4_a4 q = px[k];
+        x[4 * k] = q.x, x[4 * k + 1] = q.y, x[4 * k + 2] = q.z, x[4 * k + 3] = q.w;
+      }
     } else {  // the one chunk that straddles the wrap (i = 224..226 -> 621..623, i = 227.. -> 0..)
 #pragma unroll
       for (int k = 0; k < 16; k++) x[k] = mt[k < 3 ? 621 + k : k - 3];
