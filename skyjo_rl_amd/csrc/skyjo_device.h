@@ -224,10 +224,11 @@ struct MtStream {
     if (!issued) refill_issue();
     refill_finish();
   }
-  // Called every fourth draw of the dealing kernel's shuffle loop, where the active lanes are converged.
-  // When every lane has room for a chunk: finish the chunk whose loads were started at the previous call
-  // and start the next one.  A lane whose ring ran dry (fewer than `need` draws left) is served on its own.
-  // One code copy of issue / finish serves both cases (the loop runs once unless some lane is dry).
+  // Called once per 16 draws of the dealing kernel's shuffle loop, where the active lanes are converged and
+  // have each consumed the same number of draws.  Steady state: every lane has room for a chunk, so the chunk
+  // whose loads were started one call earlier is finished (twist, temper, store) and the loads of the next one
+  // are started - their latency hides behind the next 16 draws.  A lane left with fewer than `need` draws
+  // (it joined with an emptier ring) is served on its own.  One code copy of issue / finish serves both cases.
   __device__ __forceinline__ void service(int need = 0) {
     if (DEPTH < 64) return;
 #ifdef SK_STAMPS
@@ -235,12 +236,12 @@ struct MtStream {
     STAMP(3);
 #endif
 #pragma unroll 1
-    for (int pass = 0; pass < 3; pass++) {
+    for (int pass = 0; pass < 4; pass++) {
       const bool room = DEPTH - (wp - rp) >= 16;
       const bool dry = wp - rp < need;
       const bool all_room = pass == 0 && __all(room);
       if (!all_room && !__any(dry)) break;
-      if (issued && (dry || (all_room && __all(issued)))) refill_finish();
+      if (issued && (dry || all_room)) refill_finish();
       if (!issued && ((all_room && DEPTH - (wp - rp) >= 16) || wp - rp < need)) refill_issue();
     }
 #ifdef SK_STAMPS
@@ -952,30 +953,38 @@ __device__ __forceinline__ void shuffle_lds(uint8_t *lp, int base, int n, Rng &r
   r.unget();  // the prefetched draw belongs to whoever consumes the stream next
 }
 
-// Dealing-kernel form: inside the loop every lane consumes exactly one draw per iteration, so the lanes
-// fetch their next four draws from the ring together (one LDS round trip per four draws) and the ring is
-// serviced for the whole wavefront at the same points.
+// Dealing-kernel form: inside the loop every lane consumes exactly one draw per step, so the ring is serviced
+// for the whole wavefront once per 16 draws and the lanes fetch their next four draws together (one LDS round
+// trip per four draws, no selects: the four steps are unrolled).
+#define SK_SHUFFLE_STEP(q)                                                                        \
+  if (i >= 1) {                                                                                   \
+    const uint32_t v = (q) & mask;                                                                \
+    r.rp++, r.used++;                                                                             \
+    if (v <= (uint32_t)i) {                                                                       \
+      const int bv = base + (int)v, bi = base + i;                                                \
+      const uint8_t av = LB(bv);                                                                  \
+      LB(bi) = av, LB(bv) = (uint8_t)ai;                                                          \
+      i--;                                                                                        \
+      mask = 0xffffffffu >> __clz(i | 1);                                                         \
+      ai = LB(base + i);                                                                          \
+    }                                                                                             \
+  }
 __device__ __forceinline__ void shuffle_lds(uint8_t *lp, int base, int n, MtStream<64> &r) {
   int i = n - 1;
   if (i < 1) return;
   uint8_t *fp = r.fp;
   uint32_t mask = 0xffffffffu >> __clz(i);
-  uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-  int ai = LB(base + i);  // a[i] is known one iteration ahead
-  for (int t = 0; i >= 1; t++) {
-    if ((t & 3) == 0) {  // wave-uniform
-      r.service(4);
-      q0 = MT_FIFO(r.rp & 63), q1 = MT_FIFO((r.rp + 1) & 63), q2 = MT_FIFO((r.rp + 2) & 63), q3 = MT_FIFO((r.rp + 3) & 63);
-    }
-    const uint32_t sel = (uint32_t)(t & 3);
-    const uint32_t v = (sel == 0 ? q0 : sel == 1 ? q1 : sel == 2 ? q2 : q3) & mask;
-    r.rp++, r.used++;
-    if (v <= (uint32_t)i) {
-      const int av = LB(base + (int)v);
-      LB(base + i) = (uint8_t)av, LB(base + (int)v) = (uint8_t)ai;
-      i--;
-      mask = 0xffffffffu >> __clz(i | 1);
-      ai = (int)v == i ? ai : LB(base + (i < 0 ? 0 : i));  // a[v] now holds the old a[i]
+  int ai = LB(base + i);  // a[i] is read one step ahead (after a swap it is read behind the two writes)
+  while (__any(i >= 1)) {
+    r.service(16);
+#pragma unroll 1
+    for (int grp = 0; grp < 4; grp++) {
+      const uint32_t q0 = MT_FIFO(r.rp & 63), q1 = MT_FIFO((r.rp + 1) & 63), q2 = MT_FIFO((r.rp + 2) & 63),
+                     q3 = MT_FIFO((r.rp + 3) & 63);
+      SK_SHUFFLE_STEP(q0)
+      SK_SHUFFLE_STEP(q1)
+      SK_SHUFFLE_STEP(q2)
+      SK_SHUFFLE_STEP(q3)
     }
   }
 }
