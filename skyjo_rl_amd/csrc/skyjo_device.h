@@ -162,7 +162,14 @@ struct MtStream {
     if (DEPTH >= 64) {
       // the stream position idx + ahead is a multiple of 16: start the ring so that wp stays one too
       rp = (16 - (ahead & 15)) & 15;
-      for (int j = 0; j < ahead; j++) MT_FIFO(rp + j) = mt_temper(mt[wrap(idx + j)]);
+      for (int j0 = 0; j0 < ahead; j0 += 16) {  // 16 independent loads per round trip
+        uint32_t t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k] = j0 + k < ahead ? mt[wrap(idx + j0 + k)] : 0u;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+          if (j0 + k < ahead) MT_FIFO(rp + j0 + k) = mt_temper(t[k]);
+      }
       wp = rp + ahead;
     } else {
       pend = ahead;
