@@ -189,6 +189,10 @@ int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
  * dealing kernel (1..1024, default 64).  Every game owns a bank of two pre-dealt episodes and the dealing kernel
  * adds at most one per game and run; a finished game whose bank is empty deals in place (slow path, same result). */
 #define SKYJO_OPT_DEAL_INTERVAL 1
+/* SKYJO_OPT_OVERLAP: 1 = the dealing kernel runs on a stream of its own beside the step kernels that follow it
+ * (its episodes are published one dealing cycle later), 0 = it runs in line on the caller's stream.  Results do
+ * not depend on this setting. */
+#define SKYJO_OPT_OVERLAP 2
 int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value);
 
 /* host-pointer conveniences for small batches (single-game AEC view): synchronous */

@@ -42,7 +42,14 @@ struct skyjo_vec {
   size_t lds_bytes = 0, lds_tile = 0;
   bool seeded = false;
   int pending_iters = 0;  // lockstep iterations since the dealing kernel last ran
-  int deal_every_iters = kDealEveryIters;  // k_step launches between two k_deal launches inside skyjo_vec_rollout
+  int deal_every_iters = kDealEveryIters;
+  // dealing pipeline: k_scan / k_publish on the caller's stream, k_deal on deal_stream when overlap is on
+  bool overlap = true;
+  hipStream_t deal_stream = nullptr;
+  hipEvent_t ev_scan = nullptr, ev_dealt = nullptr;
+  bool deal_inflight = false;
+  int list_sel = 0;
+  uint32_t deal_tag = 0;  // k_step launches between two k_deal launches inside skyjo_vec_rollout
   uint64_t iter = 0;        // rollout iterations (the policy's Philox counter)
   uint64_t iters_total = 0; // lockstep iterations of any kind since the counters were reset
   // lazily allocated scratch for the *_host conveniences
@@ -78,15 +85,44 @@ int prof_events(skyjo_vec *h, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v,
   return SKYJO_OK;
 }
 
-int launch_deal(skyjo_vec *h, hipStream_t s) {
-  const int blocks = (h->P.B + SK_DEAL_SPAN - 1) / SK_DEAL_SPAN;
+// Make the episodes of the dealing launch that may still be running available (k_publish on the caller's stream).
+int publish_deals(skyjo_vec *h, hipStream_t s) {
+  if (!h->deal_inflight) return SKYJO_OK;
+  if (h->overlap) HIPCHK(hipStreamWaitEvent(s, h->ev_dealt, 0));
+  hipLaunchKernelGGL(k_publish, dim3(64), dim3(256), 0, s, h->P, h->list_sel);
+  HIPCHK(hipGetLastError());
+  h->deal_inflight = false;
+  return SKYJO_OK;
+}
+
+// One dealing cycle: publish the previous one, list the banks that are not full, deal one episode for each.
+// With overlap on, k_deal runs on its own stream beside the k_step launches that follow; its episodes are
+// published at the start of the next cycle (64 iterations later), long before a bank of SK_BANK runs dry.
+int start_deals(skyjo_vec *h, hipStream_t s) {
   int rc;
+  if ((rc = publish_deals(h, s))) return rc;
+  h->list_sel ^= 1;
+  h->deal_tag = (h->deal_tag + 1) & 0x7fffffffu;
+  if (h->deal_tag == 0) h->deal_tag = 1;
+  h->P.deal_tag = h->deal_tag;
+  HIPCHK(hipMemsetAsync(h->P.deal_count + h->list_sel, 0, sizeof(uint32_t), s));
+  hipLaunchKernelGGL(k_scan, dim3(64), dim3(256), 0, s, h->P, h->list_sel);
+  HIPCHK(hipGetLastError());
+  hipStream_t ds = s;
+  if (h->overlap) {
+    HIPCHK(hipEventRecord(h->ev_scan, s));
+    HIPCHK(hipStreamWaitEvent(h->deal_stream, h->ev_scan, 0));
+    ds = h->deal_stream;
+  }
   hipEvent_t e0, e1;
   if ((rc = prof_events(h, h->ev_deal, &e0, &e1))) return rc;
-  hipExtLaunchKernelGGL(k_deal, dim3(blocks), dim3(SK_TILE),
-                        (uint32_t)(h->lds_tile + 16384 + SK_DEAL_SPAN * sizeof(int32_t)), s, e0, e1, 0, h->P);
+  hipExtLaunchKernelGGL(k_deal, dim3(h->P.tiles), dim3(SK_TILE), (uint32_t)(h->lds_tile + 16384), ds, e0, e1, 0, h->P,
+                        h->list_sel);
   HIPCHK(hipGetLastError());
+  if (h->overlap) HIPCHK(hipEventRecord(h->ev_dealt, ds));
+  h->deal_inflight = true;
   h->pending_iters = 0;
+  if (!h->overlap) return publish_deals(h, s);
   return SKYJO_OK;
 }
 
@@ -173,9 +209,12 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   const size_t rec16 = (size_t)P.tiles * P.L.chunks * SK_TILE;
   int rc = SKYJO_OK;
   const size_t N = (size_t)cfg->num_players;
-  if ((rc = dalloc(h, &P.state, rec16)) || (rc = dalloc(h, &P.spare, 2 * rec16)) ||
-      (rc = dalloc(h, &P.spare_ready, 2 * h->G)) || (rc = dalloc(h, &P.bank_head, h->G)) ||
-      (rc = dalloc(h, &P.mt_idx, 3 * h->G)) || (rc = dalloc(h, &P.seeds, h->G)) ||
+  if ((rc = dalloc(h, &P.state, rec16)) || (rc = dalloc(h, &P.spare, SK_BANK * rec16)) ||
+      (rc = dalloc(h, &P.spare_ready, SK_BANK * h->G)) || (rc = dalloc(h, &P.bank_head, h->G)) ||
+      (rc = dalloc(h, &P.busy, h->G)) || (rc = dalloc(h, &P.cancel, h->G)) || (rc = dalloc(h, &P.done_flag, h->G)) ||
+      (rc = dalloc(h, &P.deal_list, 2 * h->G)) || (rc = dalloc(h, &P.deal_ep, 2 * h->G)) ||
+      (rc = dalloc(h, &P.deal_count, 2)) ||
+      (rc = dalloc(h, &P.mt_idx, (1 + SK_BANK) * h->G)) || (rc = dalloc(h, &P.seeds, h->G)) ||
       (rc = dalloc(h, &P.deals_consumed, h->G)) || (rc = dalloc(h, &P.rewards, h->G * N)) ||
       (rc = dalloc(h, &P.scores, h->G * N)) || (rc = dalloc(h, &P.done, h->G)) ||
       (rc = dalloc(h, &P.acc_tile, (size_t)P.tiles * 2 * SKYJO_MAX_PLAYERS)) ||
@@ -183,10 +222,18 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     skyjo_vec_destroy(h);
     return rc;
   }
-  if (cfg->rng_mode == SKYJO_RNG_MT19937 && (rc = dalloc(h, &P.mt, 3 * h->G * 624, false))) {
+  if (cfg->rng_mode == SKYJO_RNG_MT19937 && (rc = dalloc(h, &P.mt, (1 + SK_BANK) * h->G * 624, false))) {
     skyjo_vec_destroy(h);
     return rc;
   }
+  if (hipStreamCreateWithFlags(&h->deal_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_scan, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_dealt, hipEventDisableTiming) != hipSuccess) {
+    skyjo_vec_destroy(h);
+    return fail(SKYJO_E_DEVICE, "cannot create the dealing stream / events");
+  }
+  h->overlap = false;  // SKYJO_OPT_OVERLAP / SKYJO_OVERLAP=1 switch the second stream on
+  if (const char *e = getenv("SKYJO_OVERLAP")) h->overlap = atoi(e) != 0;
   *out = h;
   return SKYJO_OK;
 }
@@ -194,6 +241,9 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
 int skyjo_vec_destroy(skyjo_vec *h) {
   if (!h) return SKYJO_OK;
   (void)hipDeviceSynchronize();
+  if (h->deal_stream) (void)hipStreamDestroy(h->deal_stream);
+  if (h->ev_scan) (void)hipEventDestroy(h->ev_scan);
+  if (h->ev_dealt) (void)hipEventDestroy(h->ev_dealt);
   for (void *p : h->allocs) (void)hipFree(p);
   delete h;
   return SKYJO_OK;
@@ -217,14 +267,19 @@ int skyjo_vec_seed(skyjo_vec *h, const uint64_t *seeds_host, uint64_t base_seed,
     HIPCHK(hipMemcpyAsync(d_seeds, seeds_host, sizeof(uint64_t) * (size_t)h->P.B, hipMemcpyHostToDevice, s));
   }
   HIPCHK(hipMemsetAsync(h->P.done, 0, h->G, s));
+  int rc0;
+  if ((rc0 = publish_deals(h, s))) return rc0;  // drain the dealing pipeline of the previous seeding, if any
   hipLaunchKernelGGL(k_seed, dim3((h->P.B + 255) / 256), dim3(256), 0, s, h->P, (const uint64_t *)d_seeds, base_seed, 0,
                      h->P.B);
   HIPCHK(hipGetLastError());
   int rc;
-  // set_seed deals immediately (skyjo.py:88): deal #0 becomes the live game, deals #1 and #2 fill the bank
-  if ((rc = launch_deal(h, s))) return rc;
+  // set_seed deals immediately (skyjo.py:88): deal #0 becomes the live game, the following ones fill the bank
+  h->deal_inflight = false;
+  if ((rc = start_deals(h, s)) || (rc = publish_deals(h, s))) return rc;
   h->seeded = true;
   if ((rc = skyjo_vec_reset(h, nullptr, nullptr, stream))) return rc;
+  for (int k = 1; k < SK_BANK; k++)
+    if ((rc = start_deals(h, s)) || (rc = publish_deals(h, s))) return rc;
   if (d_seeds) {
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipFree(d_seeds));
@@ -238,15 +293,15 @@ int skyjo_vec_reset(skyjo_vec *h, const uint8_t *mask, void *records_out, void *
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (h->pending_iters > 0 && (rc = launch_deal(h, s))) return rc;  // make a next deal available where possible
+  if ((rc = publish_deals(h, s))) return rc;  // make every dealt episode available
   dim3 grid(h->P.tiles), block(SK_TILE);
   if (h->P.L.indirect)
     hipLaunchKernelGGL((k_reset<true>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out);
   else
     hipLaunchKernelGGL((k_reset<false>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out);
   HIPCHK(hipGetLastError());
-  if ((rc = launch_deal(h, s))) return rc;  // one deal per game and launch: two launches refill the bank
-  return launch_deal(h, s);
+  if ((rc = start_deals(h, s))) return rc;  // refill what was taken (one episode per game and cycle)
+  return publish_deals(h, s);
 }
 
 int skyjo_vec_step(skyjo_vec *h, const int32_t *actions, void *records_out, void *stream) {
@@ -255,7 +310,7 @@ int skyjo_vec_step(skyjo_vec *h, const int32_t *actions, void *records_out, void
   hipStream_t s = (hipStream_t)stream;
   int rc = launch_step(h, s, false, actions, (uint8_t *)records_out, nullptr, 1, 0);
   if (rc) return rc;
-  if (h->pending_iters >= h->deal_every_iters) return launch_deal(h, s);
+  if (h->pending_iters >= h->deal_every_iters) return start_deals(h, s);
   return SKYJO_OK;
 }
 
@@ -270,7 +325,7 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
     int rc = launch_step(h, s, true, nullptr, rec, actions_out, n, policy_seed);
     if (rc) return rc;
     done += n;
-    if (h->pending_iters >= h->deal_every_iters && (rc = launch_deal(h, s))) return rc;
+    if (h->pending_iters >= h->deal_every_iters && (rc = start_deals(h, s))) return rc;
     if (rec) rec += (size_t)n * h->P.B * h->P.L.rec_bytes;
     if (actions_out) actions_out += (size_t)n * h->P.B;
   }
@@ -445,10 +500,11 @@ int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream)
   if (h->P.rng_mode != SKYJO_RNG_MT19937) return fail(SKYJO_E_STATE, "seed_raw needs the MT19937 mode");
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (h->pending_iters > 0 && (rc = launch_deal(h, s))) return rc;
+  if ((rc = publish_deals(h, s))) return rc;  // nobody else may be using the stream that is re-seeded
   hipLaunchKernelGGL(k_seed_raw, dim3(1), dim3(64), 0, s, h->P, game, value);
   HIPCHK(hipGetLastError());
-  return launch_deal(h, s);
+  if ((rc = start_deals(h, s))) return rc;
+  return publish_deals(h, s);
 }
 
 int skyjo_vec_profile(skyjo_vec *h, int enable, double *step_ms, int64_t *step_launches, double *deal_ms,
@@ -493,6 +549,13 @@ int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
       if (value < 1 || value > 1024) return fail(SKYJO_E_INVALID, "deal interval must be in 1..1024");
       h->deal_every_iters = (int)value;
       return SKYJO_OK;
+    case SKYJO_OPT_OVERLAP: {
+      int rc = publish_deals(h, nullptr);  // drain the pipeline before changing its shape
+      if (rc) return rc;
+      HIPCHK(hipDeviceSynchronize());
+      h->overlap = value != 0;
+      return SKYJO_OK;
+    }
     default:
       return fail(SKYJO_E_INVALID, "unknown option");
   }

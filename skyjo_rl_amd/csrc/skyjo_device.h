@@ -22,17 +22,26 @@ struct SkCounters {
   double sum_reward[SKYJO_MAX_PLAYERS];
 };
 
+#define SK_BANK 4  // pre-dealt episodes per game
+
 struct SkParams {
   SkLayout L;
   int32_t B, tiles, rng_mode, auto_reset;
+  uint32_t deal_tag;        // id of the dealing launch that may still be running while this kernel runs
   double score_penalty, mean_reward, reward_refunded, illegal_reward;
   uint64_t game_id0;
   uint4 *state;             // [tiles][chunks][64] live games
-  uint4 *spare;             // [2][tiles][chunks][64] the two pre-dealt next episodes of every game (a 2-deep bank)
-  uint8_t *spare_ready;     // [2][tiles*64]
-  uint8_t *bank_head;       // [tiles*64] slot that is taken next; slot head^1 holds the episode after it
-  uint32_t *mt;             // [3][tiles*64][624]: [0] numpy-legacy MT19937 state, [1 + slot] undo log of that slot's deal
-  int32_t *mt_idx;          // [3][tiles*64]: [0] stream position (idx | ahead << 16), [1 + slot] position before its deal
+  uint4 *spare;             // [SK_BANK][tiles][chunks][64] the game's bank of pre-dealt next episodes
+  uint8_t *spare_ready;     // [SK_BANK][tiles*64]; the ready slots of a game are head, head+1, ... (mod SK_BANK)
+  uint8_t *bank_head;       // [tiles*64] slot that is taken next (mirrored in the record header, H_BANK)
+  uint8_t *busy;            // [tiles*64] 0, or 1 + slot while the dealing kernel owns the game's stream and that slot
+  uint8_t *cancel;          // [tiles*64] the in-flight deal was overtaken (rolled back or taken early): do not publish
+  uint32_t *done_flag;      // [tiles*64] dealing-kernel launch id that last finished a deal for the game
+  int32_t *deal_list;       // [2][tiles*64] games of the current / previous dealing launch (k_scan)
+  uint32_t *deal_ep;        // [2][tiles*64] episode index of each listed deal
+  uint32_t *deal_count;     // [2]
+  uint32_t *mt;             // [1+SK_BANK][tiles*64][624]: [0] numpy-legacy MT19937 state, [1 + slot] undo log of that slot's deal
+  int32_t *mt_idx;          // [1+SK_BANK][tiles*64]: [0] stream position (idx | ahead << 16), [1 + slot] position before its deal
   uint64_t *seeds;          // [tiles*64] value given to set_seed
   uint32_t *deals_consumed; // [tiles*64]
   double *rewards;          // [tiles*64][N]
@@ -359,23 +368,51 @@ __device__ __forceinline__ void reshuffle_discard(const SkParams &P, uint8_t *lp
   LB(H_RESH) = (uint8_t)(rs < 255 ? rs + 1 : 255);
 }
 
+// While a dealing launch overlaps this kernel, the games it deals for are marked busy: it owns their RNG stream
+// and one bank slot.  The rare paths that need the stream wait for that one deal to finish (the dealing launch
+// never waits for anybody, so this cannot deadlock; the spin is bounded all the same).
+// Returns true when that deal gave itself up (undo log overrun): it then left no record and no trace in the stream.
+__device__ __forceinline__ bool wait_deal_done(const SkParams &P, int g) {
+  uint32_t f = 0;
+  for (int spin = 0; spin < (1 << 22); spin++) {
+    f = __hip_atomic_load(&P.done_flag[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((f & 0x7fffffffu) == P.deal_tag) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return (f >> 31) != 0;
+}
+
+__device__ __forceinline__ int mt_rollback(const SkParams &P, uint32_t *mt, int g, int slot, int packed) {
+  const size_t G = (size_t)P.tiles * SK_TILE;
+  const uint32_t *undo = P.mt + ((size_t)(1 + slot) * G + g) * 624;
+  const int snap = P.mt_idx[(size_t)(1 + slot) * G + g];
+  int from = (snap & 0xffff) + (snap >> 16), to = (packed & 0xffff) + (packed >> 16);
+  from = from >= 624 ? from - 624 : from, to = to >= 624 ? to - 624 : to;
+  for (int i = from; i != to; i = i + 1 == 624 ? 0 : i + 1) mt[i] = undo[i];
+  return snap;
+}
+
 __device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *lp, uint8_t *fp, int g) {
   if (P.rng_mode == SKYJO_RNG_MT19937) {
     const size_t G = (size_t)P.tiles * SK_TILE;
     uint32_t *mt = P.mt + (size_t)g * 624;
-    int packed = P.mt_idx[g];
     // The pre-dealt episodes consumed the stream beyond this point (numpy draws the reshuffle first): roll the
-    // state back with their undo logs, newest deal first; k_deal deals them again afterwards.
-    const int head = LB(H_BANK);
-    for (int k = 1; k >= 0; k--) {
-      const int slot = head ^ k;
+    // state back with their undo logs, newest deal first; the dealing kernel deals them again afterwards.
+    const int head = LB(H_BANK) % SK_BANK;
+    const int busy = P.busy[g];
+    const bool inflight = busy && !P.cancel[g];  // (already cancelled = already finished and undone)
+    bool undo_inflight = false;
+    if (inflight) {  // a deal is in flight for this game: let it finish, then undo it as well
+      undo_inflight = !wait_deal_done(P, g);
+      P.cancel[g] = 1;
+    }
+    int packed = P.mt_idx[g];
+    if (undo_inflight) packed = mt_rollback(P, mt, g, busy - 1, packed);
+    for (int k = SK_BANK - 1; k >= 0; k--) {
+      const int slot = (head + k) % SK_BANK;
       if (P.spare_ready[(size_t)slot * G + g]) {
-        const uint32_t *undo = P.mt + ((size_t)(1 + slot) * G + g) * 624;
-        const int snap = P.mt_idx[(size_t)(1 + slot) * G + g];
-        int from = (snap & 0xffff) + (snap >> 16), to = (packed & 0xffff) + (packed >> 16);
-        from = from >= 624 ? from - 624 : from, to = to >= 624 ? to - 624 : to;
-        for (int i = from; i != to; i = i + 1 == 624 ? 0 : i + 1) mt[i] = undo[i];
-        packed = snap;
+        packed = mt_rollback(P, mt, g, slot, packed);
         P.spare_ready[(size_t)slot * G + g] = 0;
       }
     }
@@ -716,9 +753,21 @@ __device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, cons
 // ------------------------------------------------------------------------------------------
 // Take the pre-dealt next episode (SkyjoGame.reset, skyjo.py:52-74; the dealing itself is k_deal).
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_spare(const SkParams &P, uint8_t *lp, int slot, int tile, int lane) {
+  tile_load(P, P.spare + (size_t)slot * P.tiles * P.L.chunks * SK_TILE, tile, lane, lp);
+}
+
+__device__ __forceinline__ void bank_advance(const SkParams &P, uint8_t *lp, int g, int head, uint32_t dc) {
+  const uint8_t nh = (uint8_t)((head + 1) % SK_BANK);
+  P.bank_head[g] = nh;
+  LB(H_BANK) = nh;
+  P.deals_consumed[g] = dc + 1;
+  P.done[g] = 0;
+}
+
 __device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, int tile, int lane, int g) {
   const size_t G = (size_t)P.tiles * SK_TILE;
-  const int head = LB(H_BANK) & 1;
+  const int head = LB(H_BANK) % SK_BANK;
   const uint4 *s = P.spare + ((size_t)head * P.tiles + tile) * P.L.chunks * SK_TILE + lane;
   const int n = P.L.chunks;
   // flags and the first 9 chunks are requested together (the record is read even if it turns out not to be ready)
@@ -743,18 +792,15 @@ __device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, in
         LW(w + 0) = v[k].x, LW(w + 1) = v[k].y, LW(w + 2) = v[k].z, LW(w + 3) = v[k].w;
       }
   }
-  P.spare_ready[(size_t)head * G + g] = 0;  // k_deal finds the empty slots with a ballot scan
-  P.bank_head[g] = (uint8_t)(head ^ 1);
-  LB(H_BANK) = (uint8_t)(head ^ 1);
-  P.deals_consumed[g] = dc + 1;
-  P.done[g] = 0;
+  P.spare_ready[(size_t)head * G + g] = 0;  // k_scan finds the banks that are not full
+  bank_advance(P, lp, g, head, dc);
   return true;
 }
 
 // Fallback when the pre-dealt episode is not available inside a launch (a mid-game reshuffle just
 // invalidated it, or the game already took one in this launch): deal right here, on this lane, from
 // the game's current stream position.  Rare and slow (one lane active), never changes results.
-__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g);
+__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane);
 
 // ------------------------------------------------------------------------------------------
 // k_step: `iters` lockstep iterations over all tiles.  POLICY=false: one iteration with the
@@ -793,7 +839,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
         if (P.auto_reset) {
           if (!consume_spare(P, lp, tile, lane, g)) {
 #ifndef SK_EXPERIMENT_NO_RARE
-            deal_inline(P, lp, fp, g);
+            deal_inline(P, lp, fp, g, tile, lane);
 #endif
             cnt.waits++;  // counts the slow-path deals
           }
@@ -879,7 +925,7 @@ __global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *ma
   const bool want = !mask || mask[g];
   tile_load(P, P.state, tile, lane, lp);  // (the bank pointer of the game lives in its record)
   if (want) {
-    if (!consume_spare(P, lp, tile, lane, g)) deal_inline(P, lp, fp, g);
+    if (!consume_spare(P, lp, tile, lane, g)) deal_inline(P, lp, fp, g, tile, lane);
     LB(H_STATUS) = SKYJO_ST_RESET;
   }
   HdrRegs h;
@@ -901,8 +947,8 @@ __global__ void k_seed(SkParams P, const uint64_t *seeds, uint64_t base, int fir
   const size_t G = (size_t)P.tiles * SK_TILE;
   P.seeds[g] = value;
   P.deals_consumed[g] = 0;
-  P.spare_ready[g] = 0, P.spare_ready[G + g] = 0;
-  P.bank_head[g] = 0;
+  for (int k = 0; k < SK_BANK; k++) P.spare_ready[(size_t)k * G + g] = 0;
+  P.bank_head[g] = 0, P.busy[g] = 0, P.cancel[g] = 0, P.done_flag[g] = 0;
   if (P.rng_mode == SKYJO_RNG_MT19937) {
     uint32_t *mt = P.mt + (size_t)g * 624;
     uint32_t x = (uint32_t)(value + 1);
@@ -927,7 +973,7 @@ __global__ void k_seed_raw(SkParams P, int g, uint32_t value) {
   }
   P.mt_idx[g] = 0;
   const size_t G = (size_t)P.tiles * SK_TILE;
-  P.spare_ready[g] = 0, P.spare_ready[G + g] = 0;  // whatever was pre-dealt belongs to the old stream
+  for (int k = 0; k < SK_BANK; k++) P.spare_ready[(size_t)k * G + g] = 0;  // pre-dealt from the old stream
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1066,9 +1112,23 @@ __device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rn
   refresh_minima(P, lp);
 }
 
-__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g) {
+__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane) {
   const uint32_t ep = P.deals_consumed[g];
-  const uint8_t bank = LB(H_BANK);  // the bank is empty here; its head pointer survives the new record
+  const int head = LB(H_BANK) % SK_BANK;
+  const int busy = P.busy[g];
+  if (busy) {
+    // The bank is empty, but the dealing launch that overlaps this kernel is dealing exactly the episode needed
+    // (slot `head`, the next in stream order) - unless a reshuffle already rolled that deal back.
+    const bool cancelled = P.cancel[g] != 0;
+    P.cancel[g] = 1;  // taken (or superseded) here: the publishing kernel must not mark the slot ready
+    if (P.rng_mode == SKYJO_RNG_MT19937 && !cancelled) {  // the stream is shared: wait for that deal and take it
+      if (!wait_deal_done(P, g)) {
+        load_spare(P, lp, busy - 1, tile, lane);
+        bank_advance(P, lp, g, head, ep);
+        return;
+      }
+    }  // Philox deals do not depend on a stream position (and a cancelled / overrun MT deal has finished): deal here
+  }
   if (P.rng_mode == SKYJO_RNG_MT19937) {
     MtStream<16> r;
     r.open(P.mt + (size_t)g * 624, P.mt_idx[g], fp);
@@ -1079,83 +1139,120 @@ __device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint
     r.open(P.seeds[g] + 1, ep, 0u, 0u);
     deal_into_lds(P, lp, r, ep);
   }
-  LB(H_BANK) = bank;
+  LB(H_BANK) = (uint8_t)head;  // the bank is empty; its head pointer survives the new record
   P.deals_consumed[g] = ep + 1;
   P.done[g] = 0;
 }
 
-// Each workgroup (one wavefront) owns SK_DEAL_SPAN consecutive games, finds the ones whose spare
-// record is empty with a wavefront ballot + prefix popcount, compacts their ids into LDS and then
-// deals them one lane per game, so the long serial shuffles run on densely populated waves.
-#define SK_DEAL_SPAN 64
-__global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P) {
+// ------------------------------------------------------------------------------------------
+// Dealing pipeline, once per 64 lockstep iterations:
+//   k_scan    (caller's stream)  finds the banks that are not full with a wavefront ballot + prefix popcount,
+//                                appends (game, episode) to the work list and marks the games busy;
+//   k_deal    (own stream, may overlap the following k_step launches) deals one episode per listed game,
+//                                one lane per game on densely filled wavefronts;
+//   k_publish (caller's stream, after k_deal has finished) marks the new slots ready and clears busy.
+// All bank bookkeeping (head, ready flags, busy, cancel) is only ever written on the caller's stream.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scan(SkParams P, int list_sel) {
+  const size_t G = (size_t)P.tiles * SK_TILE;
+  const int lane = threadIdx.x & 63;
+  int32_t *list = P.deal_list + (size_t)list_sel * G;
+  uint32_t *eps = P.deal_ep + (size_t)list_sel * G;
+  for (int base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; base < P.B; base += gridDim.x * blockDim.x) {
+    const int g = base + lane;
+    bool need = false;
+    int slot = 0, r = 0;
+    if (g < P.B && !P.busy[g]) {
+      const int head = P.bank_head[g] % SK_BANK;
+      while (r < SK_BANK && P.spare_ready[(size_t)((head + r) % SK_BANK) * G + g]) r++;
+      need = r < SK_BANK;
+      slot = (head + r) % SK_BANK;  // slots fill in stream order
+    }
+    const unsigned long long b = __ballot(need);
+    if (b) {
+      uint32_t first = 0;
+      if (lane == 0) first = atomicAdd(&P.deal_count[list_sel], (uint32_t)__popcll(b));
+      first = __shfl(first, 0, 64);
+      if (need) {
+        const uint32_t pos = first + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        list[pos] = g;
+        eps[pos] = P.deals_consumed[g] + (uint32_t)r;
+        P.busy[g] = (uint8_t)(1 + slot);
+        P.cancel[g] = 0;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_publish(SkParams P, int list_sel) {
+  const size_t G = (size_t)P.tiles * SK_TILE;
+  const int32_t *list = P.deal_list + (size_t)list_sel * G;
+  const int count = (int)P.deal_count[list_sel];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const int g = list[i];
+    const int slot = P.busy[g] - 1;
+    if (slot >= 0 && !P.cancel[g] && P.done_flag[g] == P.deal_tag) P.spare_ready[(size_t)slot * G + g] = 1;
+    P.busy[g] = 0, P.cancel[g] = 0;
+  }
+}
+
+__global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel) {
   extern __shared__ uint32_t lds_raw[];
   const int lane = threadIdx.x;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
   uint8_t *fp = lp + P.L.chunks * 1024;
-  int32_t *work = (int32_t *)((uint8_t *)lds_raw + P.L.chunks * 1024 + 16384);  // behind the 64-word rings
   const size_t G = (size_t)P.tiles * SK_TILE;
-  const int g0 = blockIdx.x * SK_DEAL_SPAN;
+  const int count = (int)P.deal_count[list_sel];
+  const int i = blockIdx.x * SK_TILE + lane;
+  if (blockIdx.x * SK_TILE >= count) return;
   const int tile = blockIdx.x;  // stamp slot
   (void)tile;
   STAMP_DECL;
-  int count = 0;
-  for (int base = 0; base < SK_DEAL_SPAN; base += SK_TILE) {
-    const int g = g0 + base + lane;
-    bool need = false;
-    if (g < P.B) {  // at most one deal per game and launch: the older empty slot of its 2-deep bank
-      const int head = P.bank_head[g] & 1;
-      need = !P.spare_ready[(size_t)head * G + g] || !P.spare_ready[(size_t)(head ^ 1) * G + g];
-    }
-    const unsigned long long b = __ballot(need);
-    if (need) work[count + __popcll(b & ((1ull << lane) - 1ull))] = g;
-    count += __popcll(b);
-  }
-  __syncthreads();
   STAMP(0);
-  for (int base = 0; base < count; base += SK_TILE) {
-    const bool act = base + lane < count;
-    const int g = act ? work[base + lane] : 0;
-    const int head = act ? (P.bank_head[g] & 1) : 0;
-    const bool head_ready = act && P.spare_ready[(size_t)head * G + g];
-    const int slot = head_ready ? head ^ 1 : head;  // slots fill in stream order: head first
-    const uint32_t ep = act ? P.deals_consumed[g] + (head_ready ? 1u : 0u) : 0u;
-    bool mt_overrun = false;
-    if (P.rng_mode == SKYJO_RNG_MT19937) {
-      // The stream advances in place; the old value of every regenerated element goes to the slot's undo log
-      // so that a mid-game reshuffle of the live episode (which numpy would have drawn BEFORE this deal) can
-      // roll the stream back and have the deal redone (reshuffle_dispatch).
-      if (act) {
-        uint32_t *mt = P.mt + (size_t)g * 624, *undo = P.mt + ((size_t)(1 + slot) * G + g) * 624;
-        const int packed = P.mt_idx[g];
-        P.mt_idx[(size_t)(1 + slot) * G + g] = packed;
-        MtStream<64> r;
-        r.open(mt, packed, fp, undo);
-        r.stp = &st;
-        STAMP(2);
-        deal_into_lds(P, lp, r, ep);
-        P.mt_idx[g] = r.close();
-        const int generated = (r.wp & ~15) - (((16 - ((packed >> 16) & 15)) & 15) + (packed >> 16));
-        mt_overrun = generated > 624 - 64;  // the undo log is about to wrap: give this speculation up
-        if (mt_overrun) {
-          int i = (packed & 0xffff) + (packed >> 16);
-          i = i >= 624 ? i - 624 : i;
-          for (int k = 0; k < generated; k++, i = i + 1 == 624 ? 0 : i + 1) mt[i] = undo[i];
-          P.mt_idx[g] = packed;
-        }
-        STAMP(3);
-      }
-    } else if (act) {
-      PhiloxStream r;
-      r.open(P.seeds[g] + 1, ep, 0u, 0u);
+  const bool act = i < count;
+  const int g = act ? P.deal_list[(size_t)list_sel * G + i] : 0;
+  const uint32_t ep = act ? P.deal_ep[(size_t)list_sel * G + i] : 0u;
+  const int slot = act ? P.busy[g] - 1 : 0;
+  bool mt_overrun = false;
+  if (P.rng_mode == SKYJO_RNG_MT19937) {
+    // The stream advances in place; the old value of every regenerated element goes to the slot's undo log
+    // so that a mid-game reshuffle of the live episode (which numpy would have drawn BEFORE this deal) can
+    // roll the stream back and have the deal redone (reshuffle_dispatch).
+    if (act) {
+      uint32_t *mt = P.mt + (size_t)g * 624, *undo = P.mt + ((size_t)(1 + slot) * G + g) * 624;
+      const int packed = P.mt_idx[g];
+      P.mt_idx[(size_t)(1 + slot) * G + g] = packed;
+      MtStream<64> r;
+      r.open(mt, packed, fp, undo);
+      r.stp = &st;
+      STAMP(2);
       deal_into_lds(P, lp, r, ep);
+      P.mt_idx[g] = r.close();
+      const int generated = r.wp - (((16 - ((packed >> 16) & 15)) & 15) + (packed >> 16));
+      mt_overrun = generated > 624 - 64;  // the undo log is about to wrap: give this speculation up
+      if (mt_overrun) {
+        int k0 = (packed & 0xffff) + (packed >> 16);
+        k0 = k0 >= 624 ? k0 - 624 : k0;
+        for (int k = 0; k < generated; k++, k0 = k0 + 1 == 624 ? 0 : k0 + 1) mt[k0] = undo[k0];
+        P.mt_idx[g] = packed;
+      }
+      STAMP(3);
     }
-    if (act && !mt_overrun) {  // (an overrun game deals in place when its episode ends: deal_inline)
-      tile_store(P, P.spare + (size_t)slot * P.tiles * P.L.chunks * SK_TILE, g / SK_TILE, g % SK_TILE, lp);
-      P.spare_ready[(size_t)slot * G + g] = 1;
-      STAMP(4);
-    }
+  } else if (act) {
+    PhiloxStream r;
+    r.open(P.seeds[g] + 1, ep, 0u, 0u);
+    deal_into_lds(P, lp, r, ep);
   }
+  if (act) {
+    if (!mt_overrun)  // (an overrun game deals in place when its episode ends: deal_inline)
+      tile_store(P, P.spare + (size_t)slot * P.tiles * P.L.chunks * SK_TILE, g / SK_TILE, g % SK_TILE, lp);
+    STAMP(4);
+  }
+  // hand the finished deals over: every store above must be visible device-wide before the flag is
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (act)
+    __hip_atomic_store(&P.done_flag[g], P.deal_tag | (mt_overrun ? 0x80000000u : 0u), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
 #ifdef SK_STAMPS
   if (lane == 0 && tile < P.tiles)
     for (int k = 0; k < 8; k++) P.stamps[(size_t)(P.tiles + tile) * 8 + k] += st.acc[k];

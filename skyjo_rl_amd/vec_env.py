@@ -227,6 +227,10 @@ class SkyjoVecEnv:
     def set_deal_interval(self, n):
         _lib.check(self._L.skyjo_vec_set_option(self._h, 1, int(n)))
 
+    def set_overlap(self, on):
+        """Run the dealing kernel on its own stream beside the step kernels (results do not depend on it)."""
+        _lib.check(self._L.skyjo_vec_set_option(self._h, 2, int(bool(on))))
+
 
     def reset_counters(self):
         _lib.check(self._L.skyjo_vec_reset_counters(self._h, None))
