@@ -116,8 +116,14 @@ int start_deals(skyjo_vec *h, hipStream_t s) {
   }
   hipEvent_t e0, e1;
   if ((rc = prof_events(h, h->ev_deal, &e0, &e1))) return rc;
-  hipExtLaunchKernelGGL(k_deal, dim3(h->P.tiles), dim3(SK_TILE), (uint32_t)(h->lds_tile + 16384), ds, e0, e1, 0, h->P,
-                        h->list_sel);
+  // fixed player counts deal from a 41-word strip per lane (deck + scratch); the generic kernel needs the tile + ring
+  const uint32_t lds_compact = 41 * 256, lds_generic = (uint32_t)(h->lds_tile + 16384);
+  switch (h->P.L.N) {
+    case 2: hipExtLaunchKernelGGL(k_deal<2>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel); break;
+    case 3: hipExtLaunchKernelGGL(k_deal<3>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel); break;
+    case 4: hipExtLaunchKernelGGL(k_deal<4>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel); break;
+    default: hipExtLaunchKernelGGL(k_deal<0>, dim3(h->P.tiles), dim3(SK_TILE), lds_generic, ds, e0, e1, 0, h->P, h->list_sel); break;
+  }
   HIPCHK(hipGetLastError());
   if (h->overlap) HIPCHK(hipEventRecord(h->ev_dealt, ds));
   h->deal_inflight = true;

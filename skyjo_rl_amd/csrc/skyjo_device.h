@@ -1042,6 +1042,198 @@ __device__ __forceinline__ void shuffle_lds(uint8_t *lp, int base, int n, MtStre
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Dealing kernel, fixed player count: chunk-aligned MT19937 stream held in registers.
+// The 16 tempered outputs of the current chunk live in 16 VGPRs and the shuffle loop is unrolled 16 times, so
+// step s of a block consumes register s.  A lane that enters in the middle of a chunk (leftover outputs of its
+// previous session) or finishes a shuffle in the middle of one simply skips the steps before its position;
+// from then on every lane is aligned to chunk boundaries, all lanes need their next chunk at the same block
+// boundary, and the 33 loads of that chunk were started one block earlier.  No LDS ring, no selects.
+// ------------------------------------------------------------------------------------------
+struct MtChunkStream {
+  uint32_t *mt, *undo;
+  int base, pos, gen, chunks_made;  // outputs R[pos..15] of chunk `base` are unconsumed; next chunk starts at gen
+  uint32_t R[16], o[17], x[16];
+  bool issued;
+  __device__ __forceinline__ static int wrap(int v) { return v >= 624 ? v - 624 : v; }
+  __device__ __forceinline__ void open(uint32_t *mt_, int packed, uint32_t *undo_) {
+    mt = mt_, undo = undo_, issued = false, chunks_made = 0;
+    int idx = packed & 0xffff;
+    idx = idx >= 624 ? 0 : idx;
+    const int ahead = packed >> 16;  // <= 16: outputs idx .. idx+ahead-1 are already regenerated in memory
+    gen = wrap(idx + ahead);  // always a multiple of 16
+    base = gen == 0 ? 608 : gen - 16;
+    pos = 16 - ahead;  // 16: nothing pending, the first block starts with a refill
+    if (ahead > 0) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) R[k] = mt_temper(mt[base + k]);
+    }
+  }
+  __device__ __forceinline__ int close() const { return wrap(base + pos) | (((16 - pos) & 31) << 16); }
+  __device__ __forceinline__ void issue() {
+    const int c = gen;
+    const uint4 *po = (const uint4 *)(mt + c);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint4 q = po[k];
+      o[4 * k] = q.x, o[4 * k + 1] = q.y, o[4 * k + 2] = q.z, o[4 * k + 3] = q.w;
+    }
+    o[16] = mt[c + 16 == 624 ? 0 : c + 16];
+    if (c != 224) {
+      typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+      const u32x4_a4 *px = (const u32x4_a4 *)(mt + (c < 224 ? c + 397 : c - 227));
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32x4_a4 q = px[k];
+        x[4 * k] = q.x, x[4 * k + 1] = q.y, x[4 * k + 2] = q.z, x[4 * k + 3] = q.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; k++) x[k] = mt[k < 3 ? 621 + k : k - 3];
+    }
+    issued = true;
+  }
+  __device__ __forceinline__ void finish() {  // regenerate chunk `gen` in place, keep the old values in the undo log
+    const int c = gen;
+    uint32_t v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      uint32_t y = (o[k] & 0x80000000u) | (o[k + 1] & 0x7fffffffu);
+      v[k] = x[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      R[k] = mt_temper(v[k]);
+    }
+    uint4 *pm = (uint4 *)(mt + c), *pu = (uint4 *)(undo + c);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      pm[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+      pu[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    }
+    base = c, pos = 0, chunks_made++;
+    gen = c + 16 == 624 ? 0 : c + 16;
+    issued = false;
+  }
+};
+
+#define SK_CHUNK_BODY(sidx)                                                                       \
+  {                                                                                               \
+    const uint32_t v = r.R[sidx] & mask;                                                          \
+    r.pos = (sidx) + 1;                                                                           \
+    if (v <= (uint32_t)i) {                                                                       \
+      const int bv = base + (int)v, bi = base + i;                                                \
+      const uint8_t av = LB(bv);                                                                  \
+      LB(bi) = av, LB(bv) = (uint8_t)ai;                                                          \
+      i--;                                                                                        \
+      mask = 0xffffffffu >> __clz(i | 1);                                                         \
+      ai = LB(base + i);                                                                          \
+    }                                                                                             \
+  }
+#define SK_CHUNK_STEP_P(sidx) if (r.pos == (sidx) && i >= 1) SK_CHUNK_BODY(sidx)
+#define SK_CHUNK_STEP_U(sidx) if (i >= 1) SK_CHUNK_BODY(sidx)
+#define SK_16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+__device__ __forceinline__ void shuffle_lds(uint8_t *lp, int base, int n, MtChunkStream &r) {
+  int i = n - 1;
+  if (i < 1) return;
+  uint32_t mask = 0xffffffffu >> __clz(i);
+  int ai = LB(base + i);
+  // prologue: use up what is left of the lane's current chunk (a lane may enter anywhere inside one)
+  if (r.pos < 16) { SK_16(SK_CHUNK_STEP_P) }
+  if (i >= 1 && !r.issued) r.issue();
+  // main loop: every lane still shuffling is at a chunk boundary, so the refill is unconditional and the next
+  // chunk's loads are in flight during the 16 steps
+  while (i >= 1) {
+    r.finish();
+    r.issue();
+    SK_16(SK_CHUNK_STEP_U)
+  }
+}
+
+// Compact deal (fixed player count NP): only the 150-byte deck and a 12-byte scratch live in LDS
+// (bytes 0..149 and 152..163 of the lane's strip, 41 words); the game record is assembled in registers.
+// Same RNG order as deal_into_lds: shuffle(150) -> shuffle(rest) -> NP x permutation(12)[:2].
+template <int NP, class Rng>
+__device__ __forceinline__ void deal_compact(const SkParams &P, uint8_t *lp, Rng &r, uint32_t episode, uint4 *dst) {
+  constexpr int R = SK_NCARDS - 12 * NP, TMP = 152;
+  const SkLayout L = sk_make_layout(NP, P.L.indirect);
+  for (int d = 0; d < (SK_NCARDS + 3) / 4; d++) {  // _new_drawpile (skyjo.py:76-82)
+    uint32_t w = 0;
+    for (int j = 0; j < 4; j++) {
+      const int i = 4 * d + j;
+      w |= (i < SK_NCARDS ? (uint32_t)((-2 + i / 10) & 0xff) : 0u) << (8 * j);
+    }
+    LW(d) = w;
+  }
+  int s0[NP > 0 ? NP : 1], s1[NP > 0 ? NP : 1];
+#pragma unroll 1
+  for (int seg = 0; seg < NP + 2; seg++) {  // one inlined copy of the shuffle loop for all NP + 2 shuffles
+    int base = 0, n = SK_NCARDS;
+    if (seg == 1) base = 12 * NP, n = R;  // the rest is shuffled where it lies (skyjo.py:68-70)
+    if (seg >= 2) {
+      LW(TMP / 4) = 0x03020100u, LW(TMP / 4 + 1) = 0x07060504u, LW(TMP / 4 + 2) = 0x0b0a0908u;  // arange(12)
+      base = TMP, n = 12;
+    }
+    shuffle_lds(lp, base, n, r);
+    if (seg >= 2) {
+      const int a = LB(TMP), b = LB(TMP + 1);
+#pragma unroll
+      for (int p = 0; p < NP; p++)
+        if (seg - 2 == p) s0[p] = a, s1[p] = b;
+    }
+  }
+  // ---- assemble the record (skyjo_layout.h) in registers ----
+  uint32_t rec[18 * 4 + 8];
+  const int nwords = L.chunks * 4;
+#pragma unroll
+  for (int w = 0; w < 18 * 4 + 8; w++) rec[w] = 0;
+  auto setb = [&](int off, uint32_t val) { rec[off >> 2] |= (val & 0xffu) << ((off & 3) * 8); };
+  const int last = LI(SK_NCARDS - 1);
+  int best = 0, bs = -1000, ms = 1000;
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    const int c0 = LI(12 * p + s0[p]), c1 = LI(12 * p + s1[p]), sum = c0 + c1;
+    if (sum > bs) bs = sum, best = p;  // first argmax of revealed sums (skyjo.py:105-125)
+    ms = sum < ms ? sum : ms;
+    setb(L.off_sums + 2 * p, (uint32_t)sum), setb(L.off_sums + 2 * p + 1, (uint32_t)(sum >> 8));
+    setb(L.off_hidden + p, 10);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {  // vis row: 15 everywhere but the two open slots
+      uint32_t w = 0x0f0f0f0fu;
+      if ((s0[p] >> 2) == j) w = (w & ~(0xffu << ((s0[p] & 3) * 8))) | (((uint32_t)c0 & 0xffu) << ((s0[p] & 3) * 8));
+      if ((s1[p] >> 2) == j) w = (w & ~(0xffu << ((s1[p] & 3) * 8))) | (((uint32_t)c1 & 0xffu) << ((s1[p] & 3) * 8));
+      rec[(L.off_vis >> 2) + 3 * p + j] = w;
+      rec[(L.off_cards >> 2) + 3 * p + j] = LW(3 * p + j);
+    }
+    if (!L.indirect) {  // direct observation: open cards are counted too (skyjo.py:160,236-248)
+#pragma unroll
+      for (int w = 4; w <= 8; w++) {
+        const int b0 = H_HIST + 2 + c0, b1 = H_HIST + 2 + c1;
+        rec[w] += ((b0 >> 2) == w ? 1u << ((b0 & 3) * 8) : 0u) + ((b1 >> 2) == w ? 1u << ((b1 & 3) * 8) : 0u);
+      }
+    }
+  }
+  {
+    const int bl = H_HIST + 2 + last;
+#pragma unroll
+    for (int w = 4; w <= 8; w++) rec[w] += (bl >> 2) == w ? 1u << ((bl & 3) * 8) : 0u;
+  }
+#pragma unroll
+  for (int d = 0; d < (SK_NCARDS + 3) / 4; d++) {  // draw pile = rest[0 .. R-2], discard pile = [rest[R-1]] at the far end
+    uint32_t m = 0;
+    for (int j = 0; j < 4; j++)
+      if (4 * d + j < R - 1) m |= 0xffu << (8 * j);
+    uint32_t w = 3 * NP + d < (SK_NCARDS + 3) / 4 ? (LW(3 * NP + d) & m) : 0u;
+    if (d == (SK_NCARDS - 1) / 4) w |= ((uint32_t)last & 0xffu) << (((SK_NCARDS - 1) & 3) * 8);
+    rec[(L.off_pile >> 2) + d] = w;
+  }
+  rec[0] = (uint32_t)best << 8 | (uint32_t)F_VALID << 16 | (uint32_t)SKYJO_ST_RESET << 24;
+  rec[1] = (uint32_t)(R - 1) | 1u << 8 | ((uint32_t)last & 0xffu) << 24;
+  rec[2] = (uint32_t)SKYJO_HAND_NONE << 24;
+  rec[3] = episode;
+  setb(H_MINSUM, (uint32_t)(ms < 127 ? ms : 127)), setb(H_MINHID, 10);
+#pragma unroll
+  for (int c = 0; c < 18 + 2; c++)
+    if (4 * c < nwords) dst[(size_t)c * SK_TILE] = make_uint4(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]);
+}
+
 template <class Rng>
 __device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rng &r, uint32_t episode) {
   const int N = P.L.N, pb = P.L.off_pile, R = SK_NCARDS - 12 * N;
@@ -1196,11 +1388,11 @@ __global__ __launch_bounds__(256) void k_publish(SkParams P, int list_sel) {
   }
 }
 
+template <int NP>
 __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel) {
   extern __shared__ uint32_t lds_raw[];
   const int lane = threadIdx.x;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
-  uint8_t *fp = lp + P.L.chunks * 1024;
   const size_t G = (size_t)P.tiles * SK_TILE;
   const int count = (int)P.deal_count[list_sel];
   const int i = blockIdx.x * SK_TILE + lane;
@@ -1213,6 +1405,7 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel) {
   const int g = act ? P.deal_list[(size_t)list_sel * G + i] : 0;
   const uint32_t ep = act ? P.deal_ep[(size_t)list_sel * G + i] : 0u;
   const int slot = act ? P.busy[g] - 1 : 0;
+  uint4 *dst = P.spare + ((size_t)slot * P.tiles + g / SK_TILE) * P.L.chunks * SK_TILE + g % SK_TILE;
   bool mt_overrun = false;
   if (P.rng_mode == SKYJO_RNG_MT19937) {
     // The stream advances in place; the old value of every regenerated element goes to the slot's undo log
@@ -1222,13 +1415,24 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel) {
       uint32_t *mt = P.mt + (size_t)g * 624, *undo = P.mt + ((size_t)(1 + slot) * G + g) * 624;
       const int packed = P.mt_idx[g];
       P.mt_idx[(size_t)(1 + slot) * G + g] = packed;
-      MtStream<64> r;
-      r.open(mt, packed, fp, undo);
-      r.stp = &st;
-      STAMP(2);
-      deal_into_lds(P, lp, r, ep);
-      P.mt_idx[g] = r.close();
-      const int generated = r.wp - (((16 - ((packed >> 16) & 15)) & 15) + (packed >> 16));
+      int generated;
+      if (NP > 0) {
+        MtChunkStream r;
+        r.open(mt, packed, undo);
+        STAMP(2);
+        deal_compact<NP>(P, lp, r, ep, dst);
+        P.mt_idx[g] = r.close();
+        generated = r.chunks_made * 16;
+      } else {
+        uint8_t *fp = lp + P.L.chunks * 1024;
+        MtStream<64> r;
+        r.open(mt, packed, fp, undo);
+        r.stp = &st;
+        STAMP(2);
+        deal_into_lds(P, lp, r, ep);
+        P.mt_idx[g] = r.close();
+        generated = r.wp - (((16 - ((packed >> 16) & 15)) & 15) + (packed >> 16));
+      }
       mt_overrun = generated > 624 - 64;  // the undo log is about to wrap: give this speculation up
       if (mt_overrun) {
         int k0 = (packed & 0xffff) + (packed >> 16);
@@ -1241,11 +1445,11 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel) {
   } else if (act) {
     PhiloxStream r;
     r.open(P.seeds[g] + 1, ep, 0u, 0u);
-    deal_into_lds(P, lp, r, ep);
+    if (NP > 0) deal_compact<NP>(P, lp, r, ep, dst);
+    else deal_into_lds(P, lp, r, ep);
   }
   if (act) {
-    if (!mt_overrun)  // (an overrun game deals in place when its episode ends: deal_inline)
-      tile_store(P, P.spare + (size_t)slot * P.tiles * P.L.chunks * SK_TILE, g / SK_TILE, g % SK_TILE, lp);
+    if (NP == 0) tile_store(P, P.spare + (size_t)slot * P.tiles * P.L.chunks * SK_TILE, g / SK_TILE, g % SK_TILE, lp);
     STAMP(4);
   }
   // hand the finished deals over: every store above must be visible device-wide before the flag is
