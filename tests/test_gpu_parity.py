@@ -203,12 +203,13 @@ def test_rollout_vs_oracle(N, ind, rng_mode, B):
     eng.close()
 
 
-@pytest.mark.parametrize("interval", [1, 16, 1000])
-@pytest.mark.parametrize("N,rng_mode", [(2, 0), (12, 0), (1, 1)])
-def test_deal_cadence_does_not_change_results(N, rng_mode, interval):
+@pytest.mark.parametrize("interval,overlap", [(1, False), (16, False), (1000, False), (8, True), (64, True)])
+@pytest.mark.parametrize("N,rng_mode", [(2, 0), (3, 0), (12, 0), (1, 1), (1, 0), (8, 1)])
+def test_deal_cadence_does_not_change_results(N, rng_mode, interval, overlap):
     """However rarely the dealing kernel runs (bank of pre-dealt episodes full, partly filled or empty - then the
-    lane deals in place), and however often a mid-game reshuffle rolls the stream back (N=12), every step equals
-    the oracle's."""
+    lane deals in place), whether it runs in line or on its own stream beside the step kernels (then the rare
+    stream users wait for the one deal in flight for their game), and however often a mid-game reshuffle rolls
+    the stream back (N=12: ~17 per episode), every step equals the oracle's."""
     import torch
 
     B = 192
@@ -216,6 +217,7 @@ def test_deal_cadence_does_not_change_results(N, rng_mode, interval):
                reward_refunded=0.001, rng_mode=rng_mode, auto_reset=True)
     eng = _engine(B, **cfg)
     eng.set_deal_interval(interval)
+    eng.set_overlap(overlap)
     ora = _oracle_vec(num_envs=B, **cfg)
     eng.seed(None, 31)
     ora.seed(None, 31)
