@@ -113,9 +113,9 @@ struct Stamps {
 #define STAMP(i)                                                 \
   do {                                                           \
     __builtin_amdgcn_sched_barrier(0);                           \
-    __builtin_amdgcn_s_waitcnt(0);                               \
+    __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) only: stores stay in flight as in the shipped build */ \
     unsigned long long st_n = __builtin_amdgcn_s_memtime();      \
-    __builtin_amdgcn_s_waitcnt(0);                               \
+    __builtin_amdgcn_s_waitcnt(0xc07f);                          \
     st.acc[i] += st_n - st.t;                                    \
     st.t = st_n;                                                 \
     __builtin_amdgcn_sched_barrier(0);                           \
@@ -476,6 +476,46 @@ __device__ __forceinline__ void finish_game(const SkParams &P, uint8_t *lp, uint
   P.done[g] = 1;
 }
 
+// The same for a compile-time player count: card rows come in as dwords, scores stay in registers.
+template <int NP>
+__device__ __forceinline__ void finish_game_fixed(const SkParams &P, uint8_t *lp, uint8_t *ap, int g, int finisher) {
+  double *sc = P.scores + (size_t)g * NP, *rw = P.rewards + (size_t)g * NP;
+  int s[NP], refunded[NP];
+  int mn = 0, fs = 0;
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    const int cw = (P.L.off_cards + 12 * p) >> 2;
+    const uint32_t c0 = LW(cw), c1 = LW(cw + 1), c2 = LW(cw + 2);
+    refunded[p] = LB(P.L.off_refunded + p);
+    const uint32_t tri[4] = {c0 & 0xffffffu, (c0 >> 24) | ((c1 & 0xffffu) << 8), (c1 >> 16) | ((c2 & 0xffu) << 16), c2 >> 8};
+    int t = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int t0 = (int)(int8_t)tri[c], t1 = (int)(int8_t)(tri[c] >> 8), t2 = (int)(int8_t)(tri[c] >> 16);
+      t += (t0 == t1 && t1 == t2) ? 0 : t0 + t1 + t2;  // skyjo.py:488-493, hidden cards included
+    }
+    s[p] = t;
+    mn = (p == 0 || t < mn) ? t : mn;
+    fs = p == finisher ? t : fs;
+  }
+  const bool penal = mn != fs;  // skyjo.py:496-497
+  double d[NP], sum = 0.0;
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    d[p] = (penal && p == finisher) ? (double)s[p] * P.score_penalty : (double)s[p];
+    sum += d[p];  // NP < 8: numpy's pairwise sum is the plain left-to-right sum
+  }
+  const double mean = sum / (double)NP;
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    double r = (-d[p] + mean) + P.mean_reward;
+    if (P.reward_refunded != 0.0) r += (double)refunded[p] * P.reward_refunded;
+    sc[p] = d[p], rw[p] = r;
+    acc_add(ap, p, d[p]), acc_add(ap, NP + p, r);
+  }
+  P.done[g] = 1;
+}
+
 // ------------------------------------------------------------------------------------------
 // Hot path.  The three header words live in registers (HdrRegs) for a whole launch; one turn costs
 // three dependent LDS round trips: (A) the acting player's card / vis rows, (B) the pile byte that
@@ -548,7 +588,7 @@ __device__ __forceinline__ int policy_pick(int phase, uint32_t q0, uint32_t q1, 
 // v0..v2: the acting player's vis row (already loaded by the caller for the policy).
 // Caller guarantees the game is valid and not done.
 // ------------------------------------------------------------------------------------------
-template <bool INDIRECT>
+template <bool INDIRECT, int NP>
 __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uint8_t *fp, uint8_t *ap, HdrRegs &h, uint32_t v0,
                                              uint32_t v1, uint32_t v2, int a, int g, LaneCounters &cnt, Stamps &st) {
   const int N = P.L.N;
@@ -582,7 +622,8 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
     if (LB(P.L.off_hidden + p) == 0) {
       h.w0 |= (uint32_t)(F_TERMINATED | F_DONE) << 16;
       LB(H_FINISHER) = (uint8_t)p;
-      finish_game(P, lp, fp, ap, g, p);
+      if (NP > 0 && NP < 8) finish_game_fixed<(NP > 0 && NP < 8) ? NP : 1>(P, lp, ap, g, p);
+      else finish_game(P, lp, fp, ap, g, p);
       cnt.episodes++;
       cnt.sum_len += eplen;
       return;  // nothing drawn, turn not advanced (skyjo.py:350-356)
@@ -629,6 +670,9 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
     const int s = LSH(P.L.off_sums + 2 * q), hq = LB(P.L.off_hidden + q);
     oms = (q != p && s < oms) ? s : oms, omh = (q != p && hq < omh) ? hq : omh;
   }
+#ifdef SK_STAMPS_FINE
+  STAMP(5);
+#endif
   int top;
   if (a < 12) {  // swap hand card with slot a; the old card (open or hidden) goes to the discard pile
     const int old = byte3(c0, c1, c2, a);
@@ -659,7 +703,9 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
     if (!INDIRECT) hist_add(lp, c, 1);
     top = hand;
   }
-  // _remask_refunded_player_cards_jit (skyjo.py:431-469): all 4 columns of the acting player
+  // _remask_refunded_player_cards_jit (skyjo.py:431-469): all 4 columns of the acting player, every place action
+  // (checking only the touched column - the only one that can have become complete outside injected states -
+  // measured slower: the four straight-line checks are cheaper than the extra branches)
   {
     bool any = false;
 #pragma unroll
@@ -713,13 +759,17 @@ __device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, cons
   const uint32_t q0 = LW(vq), q1 = LW(vq + 1), q2 = LW(vq + 2);
   uint32_t m[8];
   {
-    const uint32_t pm = phase ? 0xffffffffu : 0u;
-    m[0] = swar_nonzero01(q0 ^ 0xf2f2f2f2u) & pm;  // vis != -14  <=> players_masked != 0
-    m[1] = swar_nonzero01(q1 ^ 0xf2f2f2f2u) & pm;
-    m[2] = swar_nonzero01(q2 ^ 0xf2f2f2f2u) & pm;
-    m[3] = (swar_nonzero01(q0 ^ 0x0f0f0f0fu) ^ 0x01010101u) & pm;  // vis == 15 <=> players_masked == 2
-    m[4] = (swar_nonzero01(q1 ^ 0x0f0f0f0fu) ^ 0x01010101u) & pm;
-    m[5] = (swar_nonzero01(q2 ^ 0x0f0f0f0fu) ^ 0x01010101u) & pm;
+    m[0] = m[1] = m[2] = m[3] = m[4] = m[5] = 0u;
+    {  // (computed in both phases and masked: a branch on the phase measured 2 us slower per launch)
+      m[0] = swar_nonzero01(q0 ^ 0xf2f2f2f2u);  // vis != -14  <=> players_masked != 0
+      m[1] = swar_nonzero01(q1 ^ 0xf2f2f2f2u);
+      m[2] = swar_nonzero01(q2 ^ 0xf2f2f2f2u);
+      m[3] = swar_nonzero01(q0 ^ 0x0f0f0f0fu) ^ 0x01010101u;  // vis == 15 <=> players_masked == 2
+      m[4] = swar_nonzero01(q1 ^ 0x0f0f0f0fu) ^ 0x01010101u;
+      m[5] = swar_nonzero01(q2 ^ 0x0f0f0f0fu) ^ 0x01010101u;
+      const uint32_t pm = phase ? 0xffffffffu : 0u;
+      m[0] &= pm, m[1] &= pm, m[2] &= pm, m[3] &= pm, m[4] &= pm, m[5] &= pm;
+    }
     m[6] = (phase ? 0u : 0x0101u) | (((h.w0 >> 8) & 0xffu) << 16) | ((uint32_t)phase << 24);
     m[7] = (((h.w0 >> 16) & F_DONE) ? 1u : 0u) | ((h.w0 >> 24) << 8) | ((h.w2 & 0xffffu) << 16);
   }
@@ -730,9 +780,16 @@ __device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, cons
     uint4 a, b;
     a.x = LW(4), a.y = LW(5), a.z = LW(6), a.w = LW(7);
     b.x = s8 | (q0 << 24), b.y = (q0 >> 8) | (q1 << 24), b.z = (q1 >> 8) | (q2 << 24), b.w = q2 >> 8;
+#ifdef SK_EXP_COALESCED  // experiment only: right bytes, wrong places (lane-contiguous 1 KiB stores)
+    o = (uint4 *)(out - (size_t)(threadIdx.x) * 64) + threadIdx.x;
+    o[0] = a, o[64] = b;
+    o[128] = make_uint4(m[0], m[1], m[2], m[3]);
+    o[192] = make_uint4(m[4], m[5], m[6], m[7]);
+#else
     o[0] = a, o[1] = b;
     o[2] = make_uint4(m[0], m[1], m[2], m[3]);
     o[3] = make_uint4(m[4], m[5], m[6], m[7]);
+#endif
   } else {
     uint32_t *o = (uint32_t *)out;
     const int nv = 3 * P.L.N, v0 = P.L.off_vis >> 2;
@@ -797,6 +854,37 @@ __device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, in
   return true;
 }
 
+// The same in two halves for the step kernel (compile-time chunk count): `spare_issue` requests the whole
+// record, `spare_commit` lands it.  Between the two the wavefront steps its live games, which hides the
+// HBM round trip of the few lanes that are resetting (about every second iteration has one).
+constexpr int sk_chunks_of(int N) { return ((((H_END + 6 * N + 3) & ~3) + 24 * N + SK_NCARDS + 15) & ~15) / 16; }
+template <int CH>
+struct SpareRegs {
+  uint4 v[CH];
+  uint32_t dc;
+  int head;
+  uint8_t ready;
+};
+template <int CH>
+__device__ __forceinline__ void spare_issue(const SkParams &P, uint8_t *lp, int tile, int lane, int g, SpareRegs<CH> &r) {
+  const size_t G = (size_t)P.tiles * SK_TILE;
+  r.head = LB(H_BANK) % SK_BANK;
+  const uint4 *s = P.spare + ((size_t)r.head * P.tiles + tile) * CH * SK_TILE + lane;
+  r.ready = P.spare_ready[(size_t)r.head * G + g];
+  r.dc = P.deals_consumed[g];
+#pragma unroll
+  for (int k = 0; k < CH; k++) r.v[k] = s[(size_t)k * SK_TILE];
+}
+template <int CH>
+__device__ __forceinline__ bool spare_commit(const SkParams &P, uint8_t *lp, int g, const SpareRegs<CH> &r) {
+  if (!r.ready) return false;
+#pragma unroll
+  for (int k = 0; k < CH; k++) LW(4 * k + 0) = r.v[k].x, LW(4 * k + 1) = r.v[k].y, LW(4 * k + 2) = r.v[k].z, LW(4 * k + 3) = r.v[k].w;
+  P.spare_ready[(size_t)r.head * (size_t)P.tiles * SK_TILE + g] = 0;  // k_scan finds the banks that are not full
+  bank_advance(P, lp, g, r.head, r.dc);
+  return true;
+}
+
 // Fallback when the pre-dealt episode is not available inside a launch (a mid-game reshuffle just
 // invalidated it, or the game already took one in this launch): deal right here, on this lane, from
 // the game's current stream position.  Rare and slow (one lane active), never changes results.
@@ -835,9 +923,30 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
                     (uint32_t)(policy_seed >> 32), r0, r1, r2, r3);
     int a = -1;
     if (valid) {
-      if ((h.w0 >> 16) & F_DONE) {
+      const bool over = ((h.w0 >> 16) & F_DONE) != 0;
+      constexpr int CH = NP > 0 ? sk_chunks_of(NP > 0 ? NP : 1) : 1;
+      SpareRegs<CH> sp;
+      if (NP > 0 && over && P.auto_reset) spare_issue<CH>(P, lp, tile, lane, g, sp);  // lands after the live games' step
+      if (!over) {
+        const int vw = (P.L.off_vis + 12 * (int)((h.w0 >> 8) & 0xff)) >> 2;
+        const uint32_t v0 = LW(vw), v1 = LW(vw + 1), v2 = LW(vw + 2);
+        STAMP(2);
+        if (POLICY) {
+          const uint32_t sel = (uint32_t)(iter & 3);
+          a = policy_pick(h.w0 & 0xff, v0, v1, v2, sel == 0 ? r0 : sel == 1 ? r1 : sel == 2 ? r2 : r3);
+        } else {
+          a = actions[g];
+        }
+        STAMP(3);
+        apply_action<INDIRECT, NP>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st);
+#ifdef SK_STAMPS_FINE
+        STAMP(6);
+#else
+        STAMP(5);
+#endif
+      } else {
         if (P.auto_reset) {
-          if (!consume_spare(P, lp, tile, lane, g)) {
+          if (!(NP > 0 ? spare_commit<CH>(P, lp, g, sp) : consume_spare(P, lp, tile, lane, g))) {
 #ifndef SK_EXPERIMENT_NO_RARE
             deal_inline(P, lp, fp, g, tile, lane);
 #endif
@@ -850,24 +959,15 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
           h.w0 = (h.w0 & 0x00ffffffu) | ((uint32_t)SKYJO_ST_NOOP_DONE << 24);
         }
         STAMP(1);
-      } else {
-        const int vw = (P.L.off_vis + 12 * (int)((h.w0 >> 8) & 0xff)) >> 2;
-        const uint32_t v0 = LW(vw), v1 = LW(vw + 1), v2 = LW(vw + 2);
-        STAMP(2);
-        if (POLICY) {
-          const uint32_t sel = (uint32_t)(iter & 3);
-          a = policy_pick(h.w0 & 0xff, v0, v1, v2, sel == 0 ? r0 : sel == 1 ? r1 : sel == 2 ? r2 : r3);
-        } else {
-          a = actions[g];
-        }
-        STAMP(3);
-        apply_action<INDIRECT>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st);
-        STAMP(5);
       }
       if (rec_out)
         emit_record<INDIRECT>(P, lp, h, (h.w0 >> 8) & 0xff, rec_out + ((size_t)it * P.B + g) * (size_t)P.L.rec_bytes);
       if (act_out) act_out[(size_t)it * P.B + g] = a;
+#ifdef SK_STAMPS_FINE
+      STAMP(7);
+#else
       STAMP(6);
+#endif
     }
   }
   HDR_FLUSH(h);

@@ -8,6 +8,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 eng = SkyjoVecEnv(B, num_players=3)
 eng.seed(None, 0)
 rec = eng.new_records(16); act = torch.empty((16, B), dtype=torch.int32, device="cuda")
+if len(sys.argv) > 2 and sys.argv[2] == "norec": rec = act = None
 for _ in range(20): eng.rollout(16, 1, records=rec, actions=act)
 torch.cuda.synchronize()
 out = np.zeros(16, dtype=np.uint64)
