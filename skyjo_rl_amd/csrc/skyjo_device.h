@@ -618,42 +618,53 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
   h.w0 &= 0x00ffffffu;  // status OK
   cnt.steps++;
   if (phase == 0) {
-    // _action_draw_card (skyjo.py:337-374): goal check first, on the drawing player
-    if (LB(P.L.off_hidden + p) == 0) {
+    // _action_draw_card (skyjo.py:337-374): goal check first, on the drawing player.  The bytes either kind of
+    // draw could need are requested together with the goal test's hidden count: one LDS round trip.
+    const int role = (h.w1 >> 16) & 1;
+    int nd = h.w1 & 0xff;
+    const int ns = (h.w1 >> 8) & 0xff;
+    const int hidden_p = LB(P.L.off_hidden + p);
+    int pile_top = LI(pb + pile_addr(role, nd > 0 ? nd - 1 : 0));
+    const int disc_top = LI(pb + pile_addr(role ^ 1, ns > 0 ? ns - 1 : 0));
+    const int disc_below = LI(pb + pile_addr(role ^ 1, ns > 1 ? ns - 2 : 0));
+    if (hidden_p == 0) {
       h.w0 |= (uint32_t)(F_TERMINATED | F_DONE) << 16;
       LB(H_FINISHER) = (uint8_t)p;
       if (NP > 0 && NP < 8) finish_game_fixed<(NP > 0 && NP < 8) ? NP : 1>(P, lp, ap, g, p);
       else finish_game(P, lp, fp, ap, g, p);
       cnt.episodes++;
       cnt.sum_len += eplen;
+#ifdef SK_STAMPS_FINE
+      STAMP(3);
+#endif
       return;  // nothing drawn, turn not advanced (skyjo.py:350-356)
     }
-    int hand;
-    if (a == 24) {
-      int nd = h.w1 & 0xff;
-      if (nd == 0) {  // rare: works on the LDS copy of the header
-        HDR_FLUSH(h);
+    const bool from_pile = a == 24;
+    if (from_pile && nd == 0) {  // rare: works on the LDS copy of the header
+      HDR_FLUSH(h);
 #ifndef SK_EXPERIMENT_NO_RARE
-        reshuffle_dispatch(P, lp, fp, g);
+      reshuffle_dispatch(P, lp, fp, g);
 #endif
-        HDR_LOAD(h);
-        cnt.reshuffles++;
-        nd = h.w1 & 0xff;
-      }
-      nd--;
-      hand = LI(pb + pile_addr((h.w1 >> 16) & 1, nd));
-      h.w1 = (h.w1 & 0xffffff00u) | (uint32_t)nd;
+      HDR_LOAD(h);
+      cnt.reshuffles++;
+      nd = h.w1 & 0xff;
+      pile_top = LI(pb + pile_addr((h.w1 >> 16) & 1, nd - 1));
+    }
+    int hand;
+    if (from_pile) {
+      hand = pile_top;
+      h.w1 = (h.w1 & 0xffffff00u) | (uint32_t)(nd - 1);
     } else {
-      const int reg = ((h.w1 >> 16) & 1) ^ 1;
-      const int ns = (int)((h.w1 >> 8) & 0xff) - 1;
-      hand = LI(pb + pile_addr(reg, ns));
-      const int below = LI(pb + pile_addr(reg, ns > 0 ? ns - 1 : 0));
+      hand = disc_top;
       hist_add(lp, hand, -1);
-      const int top = ns > 0 ? below : -3;  // skyjo.py:254
-      h.w1 = (h.w1 & 0x00ff00ffu) | ((uint32_t)ns << 8) | (((uint32_t)top & 0xffu) << 24);
+      const int top = ns > 1 ? disc_below : -3;  // skyjo.py:254
+      h.w1 = (h.w1 & 0x00ff00ffu) | ((uint32_t)(ns - 1) << 8) | (((uint32_t)top & 0xffu) << 24);
     }
     h.w2 = (h.w2 & 0x00ffffffu) | (((uint32_t)hand & 0xffu) << 24);
     h.w0 = (h.w0 & 0xffffff00u) | 1u;  // phase = place
+#ifdef SK_STAMPS_FINE
+    STAMP(3);
+#endif
     return;
   }
   STAMP(4);
@@ -673,66 +684,55 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
 #ifdef SK_STAMPS_FINE
   STAMP(5);
 #endif
-  int top;
-  if (a < 12) {  // swap hand card with slot a; the old card (open or hidden) goes to the discard pile
-    const int old = byte3(c0, c1, c2, a);
-    LB(pb + pile_addr(reg, ns)) = (uint8_t)old;
-    ns++;
-    hist_add(lp, old, 1);
-    LB(cardb + a) = (uint8_t)hand;
-    LB(visb + a) = (uint8_t)hand;
-    put3(v0, v1, v2, a, hand);
-    if (sv == SKYJO_HAND_NONE) {
-      sum += hand;
-      hid--;
-    } else {
-      sum += hand - old;
-      if (!INDIRECT) hist_add(lp, old, -1);  // an open card leaves the table (skyjo.py:240-244)
-    }
-    if (!INDIRECT) hist_add(lp, hand, 1);
-    top = old;
-  } else {  // discard the hand card and reveal slot
-    const int c = byte3(c0, c1, c2, slot);
-    LB(pb + pile_addr(reg, ns)) = (uint8_t)hand;
-    ns++;
-    hist_add(lp, hand, 1);
-    LB(visb + slot) = (uint8_t)c;
-    put3(v0, v1, v2, slot, c);
-    hid--;
-    sum += c;
-    if (!INDIRECT) hist_add(lp, c, 1);
-    top = hand;
+  // one straight-line update for both kinds of place action:
+  //   a < 12 : the hand card takes slot a, the card that lay there (open or hidden) goes to the discard pile
+  //   a >= 12: the hand card goes to the discard pile, slot a - 12 is revealed (its card value stays)
+  const bool swap = a < 12, was_hidden = sv == SKYJO_HAND_NONE;
+  const int under = byte3(c0, c1, c2, slot);  // the true card in the slot
+  const int shown = swap ? hand : under, gone = swap ? under : hand;
+  LB(pb + pile_addr(reg, ns)) = (uint8_t)gone;
+  ns++;
+  hist_add(lp, gone, 1);
+  LB(cardb + slot) = (uint8_t)shown;
+  LB(visb + slot) = (uint8_t)shown;
+  put3(v0, v1, v2, slot, shown);
+  sum += shown - (was_hidden ? 0 : under);
+  hid -= was_hidden ? 1 : 0;
+  if (!INDIRECT) {
+    if (!was_hidden) hist_add(lp, under, -1);  // an open card leaves the table (skyjo.py:240-244)
+    hist_add(lp, shown, 1);
   }
-  // _remask_refunded_player_cards_jit (skyjo.py:431-469): all 4 columns of the acting player, every place action
-  // (checking only the touched column - the only one that can have become complete outside injected states -
-  // measured slower: the four straight-line checks are cheaper than the extra branches)
+  int top = gone;
+  // _remask_refunded_player_cards_jit (skyjo.py:431-469): all 4 columns of the acting player, every place action.
+  // A column is complete when its three visible bytes are equal and neither hidden nor refunded; the test is
+  // branch-free and the (rare) collapse itself sits behind one branch.
   {
-    bool any = false;
+    const uint32_t tri[4] = {v0 & 0xffffffu, (v0 >> 24) | ((v1 & 0xffffu) << 8), (v1 >> 16) | ((v2 & 0xffu) << 16), v2 >> 8};
+    bool full[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-      uint32_t tri;  // the three bytes 3c, 3c+1, 3c+2
-      if (c == 0) tri = v0 & 0xffffffu;
-      else if (c == 1) tri = (v0 >> 24) | ((v1 & 0xffffu) << 8);
-      else if (c == 2) tri = (v1 >> 16) | ((v2 & 0xffu) << 16);
-      else tri = v2 >> 8;
-      const int t0 = (int)(int8_t)(tri & 0xff);
-      const bool same = ((tri >> 8) & 0xff) == (tri & 0xff) && ((tri >> 16) & 0xff) == (tri & 0xff);
-      if (same && t0 != SKYJO_HAND_NONE && t0 != SKYJO_REFUNDED) {
-        for (int k = 0; k < 3; k++) {
-          LB(cardb + 3 * c + k) = (uint8_t)(int8_t)SKYJO_REFUNDED;
-          LB(visb + 3 * c + k) = (uint8_t)(int8_t)SKYJO_REFUNDED;
-          // skyjo.py:454-458: the slice appended to the discard pile is the zeroed MASK -> three 0s
-          LB(pb + pile_addr(reg, ns)) = 0;
-          ns++;
-        }
-        hist_add(lp, 0, 3);
-        if (!INDIRECT) hist_add(lp, t0, -3);
-        sum -= 3 * t0;
-        top = 0;
-        any = true;
-      }
+      const uint32_t b0 = tri[c] & 0xffu;
+      full[c] = ((tri[c] ^ (tri[c] >> 8)) & 0xffffu) == 0 && b0 != (uint32_t)SKYJO_HAND_NONE && b0 != ((uint32_t)SKYJO_REFUNDED & 0xffu);
     }
-    if (any) LB(P.L.off_refunded + p)++;  // +1 per action, not per column (skyjo.py:418-419)
+    if (full[0] | full[1] | full[2] | full[3]) {
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+        if (full[c]) {
+          const int t0 = (int)(int8_t)(tri[c] & 0xff);
+          for (int k = 0; k < 3; k++) {
+            LB(cardb + 3 * c + k) = (uint8_t)(int8_t)SKYJO_REFUNDED;
+            LB(visb + 3 * c + k) = (uint8_t)(int8_t)SKYJO_REFUNDED;
+            // skyjo.py:454-458: the slice appended to the discard pile is the zeroed MASK -> three 0s
+            LB(pb + pile_addr(reg, ns)) = 0;
+            ns++;
+          }
+          hist_add(lp, 0, 3);
+          if (!INDIRECT) hist_add(lp, t0, -3);
+          sum -= 3 * t0;
+          top = 0;
+        }
+      LB(P.L.off_refunded + p)++;  // +1 per action, not per column (skyjo.py:418-419)
+    }
   }
   LSH(P.L.off_sums + 2 * p) = (int16_t)sum;
   LB(P.L.off_hidden + p) = (uint8_t)hid;
@@ -937,7 +937,9 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
         } else {
           a = actions[g];
         }
+#ifndef SK_STAMPS_FINE
         STAMP(3);
+#endif
         apply_action<INDIRECT, NP>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st);
 #ifdef SK_STAMPS_FINE
         STAMP(6);

@@ -16,7 +16,7 @@ _lib.check(eng._L.skyjo_vec_debug_stamps(eng._h, out.ctypes.data_as(C.c_void_p))
 for _ in range(10): eng.rollout(16, 1, records=rec, actions=act)
 torch.cuda.synchronize()
 _lib.check(eng._L.skyjo_vec_debug_stamps(eng._h, out.ctypes.data_as(C.c_void_p)))
-names = ["tile_load", "philox+reset path", "vis row load", "policy_pick", "apply: legality+draw(+finish)", "apply: place", "emit+stores", "tile_store+counters"]
+names = ["tile_load", "reset commit", "top: philox, spare issue, vis read (+pick)", "draw path (+finish)", "place: legality", "place A: reads", "place B: update (+draw join)", "emit+stores (+tile_store)"] if os.environ.get("FINE") else ["tile_load", "philox+reset path", "vis row load", "policy_pick", "apply: legality+draw(+finish)", "apply: place", "emit+stores", "tile_store+counters"]
 dn = ["scan+compact", "-", "stream open", "deal_into_lds (shuffles etc.)", "tile_store", "MT refill (wave-synchronous)", "-", "-"]
 dt = float(out[8:].sum()); dwaves = (B + 255) // 256 * 10
 for n, v in zip(dn, out[8:]):
