@@ -186,12 +186,13 @@ int skyjo_vec_profile(skyjo_vec *h, int enable, double *step_ms, int64_t *step_l
 int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
 
 /* Tunables.  SKYJO_OPT_DEAL_INTERVAL: lockstep iterations (steps or rollout iterations) between two runs of the
- * dealing kernel (1..1024, default 64).  Every game owns a bank of two pre-dealt episodes and the dealing kernel
- * adds at most one per game and run; a finished game whose bank is empty deals in place (slow path, same result). */
+ * dealing kernel (1..1024, default 64; environment override SKYJO_DEAL_INTERVAL).  Every game owns a bank of four
+ * pre-dealt episodes and a dealing run adds at most one per game; a finished game whose bank is empty deals in
+ * place (slow path, same result, counted in skyjo_vec_counters.waits). */
 #define SKYJO_OPT_DEAL_INTERVAL 1
 /* SKYJO_OPT_OVERLAP: 1 = the dealing kernel runs on a stream of its own beside the step kernels that follow it
- * (its episodes are published one dealing cycle later), 0 = it runs in line on the caller's stream.  Results do
- * not depend on this setting. */
+ * (its episodes are published one dealing cycle later), 0 = it runs in line on the caller's stream (default;
+ * environment override SKYJO_OVERLAP).  Results do not depend on this setting. */
 #define SKYJO_OPT_OVERLAP 2
 int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value);
 

@@ -240,6 +240,10 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   }
   h->overlap = false;  // SKYJO_OPT_OVERLAP / SKYJO_OVERLAP=1 switch the second stream on
   if (const char *e = getenv("SKYJO_OVERLAP")) h->overlap = atoi(e) != 0;
+  if (const char *e = getenv("SKYJO_DEAL_INTERVAL")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 1024) h->deal_every_iters = v;
+  }
   *out = h;
   return SKYJO_OK;
 }

@@ -1,0 +1,22 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): bash tools/refresh_profiles.sh
+# One pass of everything profiles/ is digested from (tools/collect_profiles.py reads gpurun_out/final/ afterwards):
+#   bench.json            python bench.py                       (the default line)
+#   trace/                rocprofv3 --kernel-trace --stats      (short bench run)
+#   pmc_fetch|write|sq/   rocprofv3 --kernel-trace --pmc ...    (separate passes, nothing else traced)
+set -u
+root=$PWD
+out=$root/gpurun_out/final
+rm -rf "$out"; mkdir -p "$out"
+export TMPDIR=/tmp
+python3 bench.py > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" --steps 320 --warmup 32 --no-cpu-baseline > "$out/trace_bench.json" 2> "$out/trace.err"; echo "trace rc=$?"
+for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "sq2 SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS"; do
+  set -- $pass; tag=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/pmc_$tag" -- python3 "$root/bench.py" --steps 64 --warmup 16 --no-cpu-baseline > "$out/pmc_$tag.json" 2> "$out/pmc_$tag.err"; echo "pmc $tag rc=$?"
+done
+cd "$root"
+# keep the merge-back small: only the csv summaries
+find "$out" -type f ! -name "*.csv" ! -name "*.json" ! -name "*.err" -delete
+du -sh "$out"
