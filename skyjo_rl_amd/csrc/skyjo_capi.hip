@@ -105,8 +105,8 @@ int start_deals(skyjo_vec *h, hipStream_t s) {
   h->deal_tag = (h->deal_tag + 1) & 0x7fffffffu;
   if (h->deal_tag == 0) h->deal_tag = 1;
   h->P.deal_tag = h->deal_tag;
-  HIPCHK(hipMemsetAsync(h->P.deal_count + h->list_sel, 0, sizeof(uint32_t), s));
-  hipLaunchKernelGGL(k_scan, dim3(64), dim3(256), 0, s, h->P, h->list_sel);
+  // (the list's counter was cleared by the previous run's publish step)
+  hipLaunchKernelGGL(k_scan, dim3((h->P.B + 255) / 256), dim3(256), 0, s, h->P, h->list_sel);
   HIPCHK(hipGetLastError());
   hipStream_t ds = s;
   if (h->overlap) {
@@ -117,18 +117,18 @@ int start_deals(skyjo_vec *h, hipStream_t s) {
   hipEvent_t e0, e1;
   if ((rc = prof_events(h, h->ev_deal, &e0, &e1))) return rc;
   // fixed player counts deal from a 41-word strip per lane (deck + scratch); the generic kernel needs the tile + ring
+  const int inl = h->overlap ? 0 : 1;  // in line: k_deal publishes its own episodes, no k_publish launch
   const uint32_t lds_compact = 41 * 256, lds_generic = (uint32_t)(h->lds_tile + 16384);
   switch (h->P.L.N) {
-    case 2: hipExtLaunchKernelGGL(k_deal<2>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel); break;
-    case 3: hipExtLaunchKernelGGL(k_deal<3>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel); break;
-    case 4: hipExtLaunchKernelGGL(k_deal<4>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel); break;
-    default: hipExtLaunchKernelGGL(k_deal<0>, dim3(h->P.tiles), dim3(SK_TILE), lds_generic, ds, e0, e1, 0, h->P, h->list_sel); break;
+    case 2: hipExtLaunchKernelGGL(k_deal<2>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel, inl); break;
+    case 3: hipExtLaunchKernelGGL(k_deal<3>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel, inl); break;
+    case 4: hipExtLaunchKernelGGL(k_deal<4>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel, inl); break;
+    default: hipExtLaunchKernelGGL(k_deal<0>, dim3(h->P.tiles), dim3(SK_TILE), lds_generic, ds, e0, e1, 0, h->P, h->list_sel, inl); break;
   }
   HIPCHK(hipGetLastError());
   if (h->overlap) HIPCHK(hipEventRecord(h->ev_dealt, ds));
-  h->deal_inflight = true;
+  h->deal_inflight = h->overlap;
   h->pending_iters = 0;
-  if (!h->overlap) return publish_deals(h, s);
   return SKYJO_OK;
 }
 

@@ -1456,10 +1456,25 @@ __global__ __launch_bounds__(256) void k_scan(SkParams P, int list_sel) {
     const int g = base + lane;
     bool need = false;
     int slot = 0, r = 0;
-    if (g < P.B && !P.busy[g]) {
+    uint32_t consumed = 0;
+    if (g < P.B) {
+      // every flag is requested before the first is looked at: one memory round trip per game, not SK_BANK + 2
+      const uint8_t busy = P.busy[g];
       const int head = P.bank_head[g] % SK_BANK;
-      while (r < SK_BANK && P.spare_ready[(size_t)((head + r) % SK_BANK) * G + g]) r++;
-      need = r < SK_BANK;
+      consumed = P.deals_consumed[g];
+      uint8_t ready[SK_BANK];
+#pragma unroll
+      for (int k = 0; k < SK_BANK; k++) ready[k] = P.spare_ready[(size_t)k * G + g];
+      bool open = true;
+#pragma unroll
+      for (int k = 0; k < SK_BANK; k++) {  // r = number of ready slots in stream order from `head`
+        uint8_t f = 0;
+#pragma unroll
+        for (int j = 0; j < SK_BANK; j++) f = (head + k) % SK_BANK == j ? ready[j] : f;
+        open = open && f != 0;
+        r += open ? 1 : 0;
+      }
+      need = !busy && r < SK_BANK;
       slot = (head + r) % SK_BANK;  // slots fill in stream order
     }
     const unsigned long long b = __ballot(need);
@@ -1470,7 +1485,7 @@ __global__ __launch_bounds__(256) void k_scan(SkParams P, int list_sel) {
       if (need) {
         const uint32_t pos = first + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
         list[pos] = g;
-        eps[pos] = P.deals_consumed[g] + (uint32_t)r;
+        eps[pos] = consumed + (uint32_t)r;
         P.busy[g] = (uint8_t)(1 + slot);
         P.cancel[g] = 0;
       }
@@ -1478,10 +1493,14 @@ __global__ __launch_bounds__(256) void k_scan(SkParams P, int list_sel) {
   }
 }
 
+// Hand a dealing run's episodes to the step kernel: on the caller's stream after k_deal when that ran on a stream
+// of its own; k_deal does the same per lane itself when it runs in line (publish_inline).  Also clears the other
+// work list's counter for the next run's k_scan.
 __global__ __launch_bounds__(256) void k_publish(SkParams P, int list_sel) {
   const size_t G = (size_t)P.tiles * SK_TILE;
   const int32_t *list = P.deal_list + (size_t)list_sel * G;
   const int count = (int)P.deal_count[list_sel];
+  if (blockIdx.x == 0 && threadIdx.x == 0) P.deal_count[list_sel ^ 1] = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     const int g = list[i];
     const int slot = P.busy[g] - 1;
@@ -1491,22 +1510,25 @@ __global__ __launch_bounds__(256) void k_publish(SkParams P, int list_sel) {
 }
 
 template <int NP>
-__global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel) {
+__global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int publish_inline) {
   extern __shared__ uint32_t lds_raw[];
   const int lane = threadIdx.x;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
   const size_t G = (size_t)P.tiles * SK_TILE;
   const int count = (int)P.deal_count[list_sel];
   const int i = blockIdx.x * SK_TILE + lane;
+  if (publish_inline && blockIdx.x == 0 && lane == 0) P.deal_count[list_sel ^ 1] = 0;  // for the next run's k_scan
   if (blockIdx.x * SK_TILE >= count) return;
   const int tile = blockIdx.x;  // stamp slot
   (void)tile;
   STAMP_DECL;
   STAMP(0);
-  const bool act = i < count;
-  const int g = act ? P.deal_list[(size_t)list_sel * G + i] : 0;
-  const uint32_t ep = act ? P.deal_ep[(size_t)list_sel * G + i] : 0u;
-  const int slot = act ? P.busy[g] - 1 : 0;
+  const bool listed = i < count;
+  const int g = listed ? P.deal_list[(size_t)list_sel * G + i] : 0;
+  const uint32_t ep = listed ? P.deal_ep[(size_t)list_sel * G + i] : 0u;
+  const int owner = listed ? P.busy[g] : 0;
+  const bool act = owner > 0;  // (an entry whose game is not marked busy would be a stale list: never dealt)
+  const int slot = act ? owner - 1 : 0;
   uint4 *dst = P.spare + ((size_t)slot * P.tiles + g / SK_TILE) * P.L.chunks * SK_TILE + g % SK_TILE;
   bool mt_overrun = false;
   if (P.rng_mode == SKYJO_RNG_MT19937) {
@@ -1554,11 +1576,20 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel) {
     if (NP == 0) tile_store(P, P.spare + (size_t)slot * P.tiles * P.L.chunks * SK_TILE, g / SK_TILE, g % SK_TILE, lp);
     STAMP(4);
   }
-  // hand the finished deals over: every store above must be visible device-wide before the flag is
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  if (act)
-    __hip_atomic_store(&P.done_flag[g], P.deal_tag | (mt_overrun ? 0x80000000u : 0u), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+  if (publish_inline) {
+    // in line on the caller's stream: no step kernel runs beside this one, so nothing can have cancelled the deal
+    // and the next kernel on the stream sees every store - mark the slot ready right here (what k_publish does)
+    if (act) {
+      if (!mt_overrun) P.spare_ready[(size_t)slot * G + g] = 1;
+      P.busy[g] = 0;
+    }
+  } else {
+    // hand the finished deals over: every store above must be visible device-wide before the flag is
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (act)
+      __hip_atomic_store(&P.done_flag[g], P.deal_tag | (mt_overrun ? 0x80000000u : 0u), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
 #ifdef SK_STAMPS
   if (lane == 0 && tile < P.tiles)
     for (int k = 0; k < 8; k++) P.stamps[(size_t)(P.tiles + tile) * 8 + k] += st.acc[k];
