@@ -40,7 +40,7 @@ struct SkParams {
   int32_t *deal_list;       // [2][tiles*64] games of the current / previous dealing launch (k_scan)
   uint32_t *deal_ep;        // [2][tiles*64] episode index of each listed deal
   uint32_t *deal_count;     // [2]
-  uint32_t *mt;             // [1+SK_BANK][tiles*64][624]: [0] numpy-legacy MT19937 state, [1 + slot] undo log of that slot's deal
+  uint32_t *mt;             // [tiles*64][624] numpy-legacy MT19937 state, advanced in place (mt_untwist steps it back)
   int32_t *mt_idx;          // [1+SK_BANK][tiles*64]: [0] stream position (idx | ahead << 16), [1 + slot] position before its deal
   uint64_t *seeds;          // [tiles*64] value given to set_seed
   uint32_t *deals_consumed; // [tiles*64]
@@ -157,13 +157,12 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t v) {
 template <int DEPTH>
 struct MtStream {
   uint32_t *mt;
-  uint32_t *undo;  // DEPTH 64 only: old values of every regenerated element are kept here (same index)
   uint8_t *fp;
   Stamps *stp = nullptr;  // diagnostics only
   int idx, gen, rp, wp, pend, used;
   __device__ __forceinline__ static int wrap(int x) { return x >= 624 ? x - 624 : x; }
-  __device__ __forceinline__ void open(uint32_t *mt_, int packed, uint8_t *fp_, uint32_t *undo_ = nullptr) {
-    mt = mt_, fp = fp_, undo = undo_;
+  __device__ __forceinline__ void open(uint32_t *mt_, int packed, uint8_t *fp_) {
+    mt = mt_, fp = fp_;
     idx = packed & 0xffff;
     idx = idx >= 624 ? 0 : idx;
     const int ahead = packed >> 16;
@@ -224,11 +223,6 @@ struct MtStream {
     uint4 *pm = (uint4 *)(mt + c);
 #pragma unroll
     for (int k = 0; k < 4; k++) pm[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
-    if (DEPTH >= 64) {
-      uint4 *pu = (uint4 *)(undo + c);
-#pragma unroll
-      for (int k = 0; k < 4; k++) pu[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
-    }
     const int w0 = wp & (DEPTH - 1);  // wp is a multiple of 16 whenever a chunk is appended
 #pragma unroll
     for (int k = 0; k < 16; k++) MT_FIFO(w0 + k) = mt_temper(v[k]);
@@ -383,13 +377,39 @@ __device__ __forceinline__ bool wait_deal_done(const SkParams &P, int g) {
   return (f >> 31) != 0;
 }
 
+// MT19937's in-place regeneration is invertible, so a deal that has to be taken back needs no log of the values it
+// overwrote.  Element i was made as  new[i] = S[i+397] ^ twist((S[i] & 0x80000000) | (S[i+1] & 0x7fffffff)) ; walking
+// backwards from the newest element, S[i+397] and S[i+1] are exactly what they were when i was made, so
+// twist(y) = new[i] ^ S[i+397]; bit 31 of twist(y) tells whether y was odd (the magic constant has it set, y >> 1 has
+// not), which gives y back: its top bit is old S[i]'s, its low 31 bits are old S[i+1]'s.  The low 31 bits of the
+// oldest element undone come from the y of the element before it, which is still in place.
+__device__ __forceinline__ uint32_t mt_untwist_y(const uint32_t *mt, int i) {
+  uint32_t t = mt[i] ^ mt[i + 397 >= 624 ? i + 397 - 624 : i + 397];
+  const uint32_t odd = t >> 31;
+  t ^= odd ? 0x9908b0dfu : 0u;
+  return (t << 1) | odd;
+}
+__device__ __forceinline__ void mt_untwist(uint32_t *mt, int from, int to) {  // undo elements [from, to) in stream order
+  if (from == to) return;
+  for (int i = to; i != from;) {
+    const int nx = i == 624 ? 0 : i;  // (to may be given as 624)
+    i = nx == 0 ? 623 : nx - 1;
+    const uint32_t y = mt_untwist_y(mt, i);
+    const int ip1 = i == 623 ? 0 : i + 1;
+    mt[ip1] = (mt[ip1] & 0x80000000u) | (y & 0x7fffffffu);
+    mt[i] = y & 0x80000000u;
+  }
+  const uint32_t y = mt_untwist_y(mt, from == 0 ? 623 : from - 1);
+  mt[from] = (mt[from] & 0x80000000u) | (y & 0x7fffffffu);
+}
+
+// Take back the deal that filled bank slot `slot`: the stream returns to where it stood before that deal.
 __device__ __forceinline__ int mt_rollback(const SkParams &P, uint32_t *mt, int g, int slot, int packed) {
   const size_t G = (size_t)P.tiles * SK_TILE;
-  const uint32_t *undo = P.mt + ((size_t)(1 + slot) * G + g) * 624;
   const int snap = P.mt_idx[(size_t)(1 + slot) * G + g];
   int from = (snap & 0xffff) + (snap >> 16), to = (packed & 0xffff) + (packed >> 16);
   from = from >= 624 ? from - 624 : from, to = to >= 624 ? to - 624 : to;
-  for (int i = from; i != to; i = i + 1 == 624 ? 0 : i + 1) mt[i] = undo[i];
+  mt_untwist(mt, from, to);
   return snap;
 }
 
@@ -398,7 +418,7 @@ __device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *l
     const size_t G = (size_t)P.tiles * SK_TILE;
     uint32_t *mt = P.mt + (size_t)g * 624;
     // The pre-dealt episodes consumed the stream beyond this point (numpy draws the reshuffle first): roll the
-    // state back with their undo logs, newest deal first; the dealing kernel deals them again afterwards.
+    // state back over them (mt_untwist), newest deal first; the dealing kernel deals them again afterwards.
     const int head = LB(H_BANK) % SK_BANK;
     const int busy = P.busy[g];
     const bool inflight = busy && !P.cancel[g];  // (already cancelled = already finished and undone)
@@ -1145,21 +1165,28 @@ __device__ __forceinline__ void shuffle_lds(uint8_t *lp, int base, int n, MtStre
 }
 
 // ------------------------------------------------------------------------------------------
-// Dealing kernel, fixed player count: chunk-aligned MT19937 stream held in registers.
-// The 16 tempered outputs of the current chunk live in 16 VGPRs and the shuffle loop is unrolled 16 times, so
-// step s of a block consumes register s.  A lane that enters in the middle of a chunk (leftover outputs of its
-// previous session) or finishes a shuffle in the middle of one simply skips the steps before its position;
-// from then on every lane is aligned to chunk boundaries, all lanes need their next chunk at the same block
-// boundary, and the 33 loads of that chunk were started one block earlier.  No LDS ring, no selects.
+// Dealing kernel, fixed player count.  Everything that decides WHICH cards are swapped (the draw, its mask,
+// the rejection test, the shuffle index) is register arithmetic on the RNG outputs alone; the deck only ever
+// receives the swaps.  So the loop takes its draws four at a time: the eight deck words the four steps touch
+// are requested together, the few ways two of those steps can meet on the same position are resolved with
+// selects in registers, and the eight results are written back fire-and-forget (LDS executes a wavefront's
+// accesses in order, the next batch's reads see them).  One LDS round trip per four draws, no branch inside.
+//
+// RNG side: a "chunk stream" hands out 16 outputs at a time in registers R[0..15].
+//   MtChunkStream      numpy-legacy MT19937, regenerated in place 16 elements at a time; the 33 loads of the next
+//                      chunk are in flight during the 16 draws of the current one.  A lane may enter in the middle
+//                      of a chunk (leftover outputs of its previous session) - the prologue of each loop skips
+//                      the outputs before its position - and from then on every lane is chunk-aligned.
+//   PhiloxChunkStream  the counter-based session of PhiloxStream, four blocks per refill.
 // ------------------------------------------------------------------------------------------
 struct MtChunkStream {
-  uint32_t *mt, *undo;
+  uint32_t *mt;
   int base, pos, gen, chunks_made;  // outputs R[pos..15] of chunk `base` are unconsumed; next chunk starts at gen
   uint32_t R[16], o[17], x[16];
   bool issued;
   __device__ __forceinline__ static int wrap(int v) { return v >= 624 ? v - 624 : v; }
-  __device__ __forceinline__ void open(uint32_t *mt_, int packed, uint32_t *undo_) {
-    mt = mt_, undo = undo_, issued = false, chunks_made = 0;
+  __device__ __forceinline__ void open(uint32_t *mt_, int packed) {
+    mt = mt_, issued = false, chunks_made = 0;
     int idx = packed & 0xffff;
     idx = idx >= 624 ? 0 : idx;
     const int ahead = packed >> 16;  // <= 16: outputs idx .. idx+ahead-1 are already regenerated in memory
@@ -1174,6 +1201,12 @@ struct MtChunkStream {
   __device__ __forceinline__ int close() const { return wrap(base + pos) | (((16 - pos) & 31) << 16); }
   __device__ __forceinline__ void issue() {
     const int c = gen;
+#ifdef SK_EXP_NOLOAD
+    for (int k = 0; k < 17; k++) o[k] = (uint32_t)(c + k) * 2654435761u ^ (uint32_t)(size_t)mt;
+    for (int k = 0; k < 16; k++) x[k] = (uint32_t)(c + k) * 40503u + (uint32_t)chunks_made;
+    issued = true;
+    return;
+#endif
     const uint4 *po = (const uint4 *)(mt + c);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1195,90 +1228,182 @@ struct MtChunkStream {
     }
     issued = true;
   }
-  __device__ __forceinline__ void finish() {  // regenerate chunk `gen` in place, keep the old values in the undo log
+  __device__ __forceinline__ void pre_loop() {  // the lane is about to run out of outputs: start the next chunk's loads
+    if (!issued) issue();
+  }
+  // Regenerate chunk `gen` in place (its loads were started a chunk earlier) and start the loads of the chunk
+  // after it.  Those loads go out BEFORE this chunk's stores: vmcnt counts in order, so a wait for loads that
+  // were issued behind stores would also wait for the stores' round trip to memory.
+  __device__ __forceinline__ void refill() {
     const int c = gen;
     uint32_t v[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      uint32_t y = (o[k] & 0x80000000u) | (o[k + 1] & 0x7fffffffu);
+      const uint32_t y = (o[k] & 0x80000000u) | (o[k + 1] & 0x7fffffffu);
       v[k] = x[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-      R[k] = mt_temper(v[k]);
-    }
-    uint4 *pm = (uint4 *)(mt + c), *pu = (uint4 *)(undo + c);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      pm[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
-      pu[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
     }
     base = c, pos = 0, chunks_made++;
     gen = c + 16 == 624 ? 0 : c + 16;
-    issued = false;
+    issue();
+#pragma unroll
+    for (int k = 0; k < 16; k++) R[k] = mt_temper(v[k]);
+#ifndef SK_EXP_NOSTORE
+    uint4 *pm = (uint4 *)(mt + c);
+#pragma unroll
+    for (int k = 0; k < 4; k++) pm[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+#endif
   }
 };
 
-#define SK_CHUNK_BODY(sidx)                                                                       \
-  {                                                                                               \
-    const uint32_t v = r.R[sidx] & mask;                                                          \
-    r.pos = (sidx) + 1;                                                                           \
-    if (v <= (uint32_t)i) {                                                                       \
-      const int bv = base + (int)v, bi = base + i;                                                \
-      const uint8_t av = LB(bv);                                                                  \
-      LB(bi) = av, LB(bv) = (uint8_t)ai;                                                          \
-      i--;                                                                                        \
-      mask = 0xffffffffu >> __clz(i | 1);                                                         \
-      ai = LB(base + i);                                                                          \
-    }                                                                                             \
+struct PhiloxChunkStream {  // same output sequence as PhiloxStream (block b -> words 4b .. 4b+3)
+  uint32_t R[16], k0, k1, blk, c1, c2, c3;
+  int pos;
+  __device__ __forceinline__ void open(uint64_t key, uint32_t episode, uint32_t resh, uint32_t domain) {
+    k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32), blk = 0, c1 = episode, c2 = resh, c3 = domain, pos = 16;
   }
-#define SK_CHUNK_STEP_P(sidx) if (r.pos == (sidx) && i >= 1) SK_CHUNK_BODY(sidx)
-#define SK_CHUNK_STEP_U(sidx) if (i >= 1) SK_CHUNK_BODY(sidx)
-#define SK_16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
-__device__ __forceinline__ void shuffle_lds(uint8_t *lp, int base, int n, MtChunkStream &r) {
-  int i = n - 1;
-  if (i < 1) return;
-  uint32_t mask = 0xffffffffu >> __clz(i);
-  int ai = LB(base + i);
-  // prologue: use up what is left of the lane's current chunk (a lane may enter anywhere inside one)
-  if (r.pos < 16) { SK_16(SK_CHUNK_STEP_P) }
-  if (i >= 1 && !r.issued) r.issue();
-  // main loop: every lane still shuffling is at a chunk boundary, so the refill is unconditional and the next
-  // chunk's loads are in flight during the 16 steps
-  while (i >= 1) {
-    r.finish();
-    r.issue();
-    SK_16(SK_CHUNK_STEP_U)
+  __device__ __forceinline__ void pre_loop() {}
+  __device__ __forceinline__ void refill() {
+#pragma unroll
+    for (int b = 0; b < 4; b++) philox4x32_10(blk + b, c1, c2, c3, k0, k1, R[4 * b], R[4 * b + 1], R[4 * b + 2], R[4 * b + 3]);
+    blk += 4, pos = 0;
+  }
+};
+
+// The lane's deck: card k is the dword at LDS byte address  dk + (k << 8)  (one card per dword: a position is an
+// address, no byte arithmetic; 150 x 256 B = 37.5 KB of LDS per wavefront, which the 2-3 dealing wavefronts per
+// CU can afford).
+#define DK_AT(addr) (*(uint32_t *)((uint8_t *)lds_raw_base + (addr)))
+
+// Legacy RandomState.shuffle (for i = n-1 .. 1: j = rk_interval(i); swap(a[i], a[j])) of the whole deck and then
+// of the rest behind the 12 NP dealt cards (skyjo.py:76-82 and :68-70,:127-138), as ONE lane-private walk: a lane
+// that accepts the last draw of the first shuffle starts the second with its very next draw, so lanes only
+// re-converge once, at the end.  A draw that is not used for a swap (rejected, lane not there yet, lane finished)
+// swaps the current position with itself.
+struct DeckWalk {
+  uint32_t pcur, pb;  // LDS addresses of a[i] and a[0] of the current shuffle
+  uint32_t n;         // i + 1: the draw v is accepted iff v < n; 0 when the lane has finished both shuffles
+  uint32_t nxt_n;     // what n becomes when the current shuffle completes (R, then 0)
+  uint32_t mask;      // rk_interval's mask for max = n - 1
+};
+template <bool PRO, int NP, class Rng>
+__device__ __forceinline__ void deck_batch(Rng &r, const int s, uint32_t *lds_raw_base, const uint32_t dk, DeckWalk &w) {
+  constexpr uint32_t R = SK_NCARDS - 12 * NP;
+  uint32_t pI[4], pJ[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t v = r.R[s + k] & w.mask;
+    const bool acc = PRO ? (v < w.n && s + k >= r.pos) : (v < w.n);
+    pI[k] = w.pcur;
+    pJ[k] = acc ? w.pb + (v << 8) : w.pcur;
+    const uint32_t d = acc ? 0xffffffffu : 0u;
+    const uint32_t n2 = w.n + d;
+    const bool t = n2 == 1u;  // this shuffle is complete (i reached 0): on to the rest, or done
+    w.n = t ? w.nxt_n : n2;
+    w.pcur = t ? dk + ((SK_NCARDS - 1) << 8) : w.pcur + (d << 8);
+    w.pb = t ? dk + ((12 * NP) << 8) : w.pb;
+    w.nxt_n = t ? 0u : w.nxt_n;
+    r.pos = t ? s + k + 1 : r.pos;  // (a lane that is still shuffling after the block gets pos = 16 from the caller)
+    w.mask = 0xffffffffu >> (__clz((int)(w.n - 1u)) & 31);
+  }
+  uint32_t cI[4], cJ[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) cI[k] = DK_AT(pI[k]), cJ[k] = DK_AT(pJ[k]);
+#ifdef SK_EXP_NODECK
+  for (int k = 0; k < 4; k++) cI[k] = pI[k], cJ[k] = pJ[k];
+#endif
+  // What step k finds at its two positions is what the batch's earlier steps left there.  Only an earlier step's
+  // j-position can be met again: its i-position lies above everything that follows (or, for an unused draw, is
+  // its j-position).  The latest writer wins, hence ascending m.
+#pragma unroll
+  for (int k = 1; k < 4; k++)
+#pragma unroll
+    for (int m = 0; m < k; m++) {
+      cI[k] = pJ[m] == pI[k] ? cI[m] : cI[k];
+      cJ[k] = pJ[m] == pJ[k] ? cI[m] : cJ[k];
+    }
+#ifndef SK_EXP_NODECK
+#pragma unroll
+  for (int k = 0; k < 4; k++) DK_AT(pI[k]) = cJ[k], DK_AT(pJ[k]) = cI[k];
+#else
+  if (cI[3] + cJ[3] + cI[2] + cJ[2] + cI[1] + cJ[1] + cI[0] + cJ[0] == 0x12345u) DK_AT(pI[0]) = 0;
+#endif
+}
+
+// _reset_card_mask (skyjo.py:96-103): choice(12, 2, replace=False) == permutation(12)[:2] per player, i.e. a full
+// 11-step shuffle of arange(12) each.  The permutation is twelve nibbles of one 64-bit register, no memory.
+struct PermWalk {
+  uint64_t pm;
+  uint32_t n, mask;   // as in DeckWalk; n == 0: all players done
+  uint32_t sh, open;  // open: byte p = slot0 | slot1 << 4 of player p; sh = 8 p
+};
+template <bool PRO, int NP, class Rng>
+__device__ __forceinline__ void perm_batch(Rng &r, const int s, PermWalk &w) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t v = r.R[s + k] & w.mask;
+    const bool acc = PRO ? (v < w.n && s + k >= r.pos) : (v < w.n);
+    const uint32_t si = 4u * (w.n - 1u) & 63u, sv = 4u * v & 63u;
+    uint64_t x = ((w.pm >> si) ^ (w.pm >> sv)) & 0xfull;
+    x = acc ? x : 0ull;
+    w.pm ^= (x << si) ^ (x << sv);
+    const uint32_t n2 = w.n + (acc ? 0xffffffffu : 0u);
+    const bool t = n2 == 1u;
+    w.open |= t ? ((uint32_t)w.pm & 0xffu) << w.sh : 0u;
+    w.sh += t ? 8u : 0u;
+    w.pm = t ? 0xBA9876543210ull : w.pm;
+    w.n = t ? (w.sh == 8u * NP ? 0u : 12u) : n2;
+    r.pos = t ? s + k + 1 : r.pos;
+    w.mask = 0xffffffffu >> (__clz((int)(w.n - 1u)) & 31);
   }
 }
 
-// Compact deal (fixed player count NP): only the 150-byte deck and a 12-byte scratch live in LDS
-// (bytes 0..149 and 152..163 of the lane's strip, 41 words); the game record is assembled in registers.
-// Same RNG order as deal_into_lds: shuffle(150) -> shuffle(rest) -> NP x permutation(12)[:2].
+#define SK_FOUR_BATCHES(CALL) CALL(0) CALL(4) CALL(8) CALL(12)
+
+// Compact deal (fixed player count NP): only the deck lives in LDS; the game record is assembled in registers.
+// RNG order: shuffle(150) -> shuffle(rest) -> NP x permutation(12)[:2].
 template <int NP, class Rng>
-__device__ __forceinline__ void deal_compact(const SkParams &P, uint8_t *lp, Rng &r, uint32_t episode, uint4 *dst) {
-  constexpr int R = SK_NCARDS - 12 * NP, TMP = 152;
+__device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_raw_base, const int lane, Rng &r, uint32_t episode,
+                                             uint4 *dst) {
+  constexpr int R = SK_NCARDS - 12 * NP;
   const SkLayout L = sk_make_layout(NP, P.L.indirect);
-  for (int d = 0; d < (SK_NCARDS + 3) / 4; d++) {  // _new_drawpile (skyjo.py:76-82)
-    uint32_t w = 0;
-    for (int j = 0; j < 4; j++) {
-      const int i = 4 * d + j;
-      w |= (i < SK_NCARDS ? (uint32_t)((-2 + i / 10) & 0xff) : 0u) << (8 * j);
-    }
-    LW(d) = w;
-  }
-  int s0[NP > 0 ? NP : 1], s1[NP > 0 ? NP : 1];
-#pragma unroll 1
-  for (int seg = 0; seg < NP + 2; seg++) {  // one inlined copy of the shuffle loop for all NP + 2 shuffles
-    int base = 0, n = SK_NCARDS;
-    if (seg == 1) base = 12 * NP, n = R;  // the rest is shuffled where it lies (skyjo.py:68-70)
-    if (seg >= 2) {
-      LW(TMP / 4) = 0x03020100u, LW(TMP / 4 + 1) = 0x07060504u, LW(TMP / 4 + 2) = 0x0b0a0908u;  // arange(12)
-      base = TMP, n = 12;
-    }
-    shuffle_lds(lp, base, n, r);
-    if (seg >= 2) {
-      const int a = LB(TMP), b = LB(TMP + 1);
+  const uint32_t dk = (uint32_t)lane * 4u;  // LDS address of the lane's card 0
+#define DKW(k) DK_AT(dk + ((k) << 8))
 #pragma unroll
-      for (int p = 0; p < NP; p++)
-        if (seg - 2 == p) s0[p] = a, s1[p] = b;
+  for (int k = 0; k < SK_NCARDS; k++) DKW(k) = (uint32_t)((-2 + k / 10) & 0xff);  // _new_drawpile (skyjo.py:76-82)
+  {
+    DeckWalk w;
+    w.pb = dk, w.pcur = dk + ((SK_NCARDS - 1) << 8), w.n = SK_NCARDS, w.nxt_n = R, w.mask = 0xffu;
+    if (r.pos < 16) {
+#define SK_CALL(s) deck_batch<true, NP>(r, s, lds_raw_base, dk, w);
+      SK_FOUR_BATCHES(SK_CALL)
+#undef SK_CALL
+      r.pos = w.n ? 16 : r.pos;
+    }
+    if (w.n) r.pre_loop();
+    while (w.n) {
+      r.refill();
+#define SK_CALL(s) deck_batch<false, NP>(r, s, lds_raw_base, dk, w);
+      SK_FOUR_BATCHES(SK_CALL)
+#undef SK_CALL
+      r.pos = w.n ? 16 : r.pos;
+    }
+  }
+  PermWalk pw;
+  pw.pm = 0xBA9876543210ull, pw.n = 12u, pw.mask = 0xfu, pw.sh = 0u, pw.open = 0u;
+  {
+    if (r.pos < 16) {
+#define SK_CALL(s) perm_batch<true, NP>(r, s, pw);
+      SK_FOUR_BATCHES(SK_CALL)
+#undef SK_CALL
+      r.pos = pw.n ? 16 : r.pos;
+    }
+    if (pw.n) r.pre_loop();
+    while (pw.n) {
+      r.refill();
+#define SK_CALL(s) perm_batch<false, NP>(r, s, pw);
+      SK_FOUR_BATCHES(SK_CALL)
+#undef SK_CALL
+      r.pos = pw.n ? 16 : r.pos;
     }
   }
   // ---- assemble the record (skyjo_layout.h) in registers ----
@@ -1287,22 +1412,30 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint8_t *lp, Rng
 #pragma unroll
   for (int w = 0; w < 18 * 4 + 8; w++) rec[w] = 0;
   auto setb = [&](int off, uint32_t val) { rec[off >> 2] |= (val & 0xffu) << ((off & 3) * 8); };
-  const int last = LI(SK_NCARDS - 1);
+  auto pack4 = [&](int k) {  // deck cards k .. k+3 as four bytes (cards beyond the deck read as 0)
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (k + j < SK_NCARDS) w |= DKW(k + j) << (8 * j);
+    return w;
+  };
+  const int last = (int)(int8_t)DKW(SK_NCARDS - 1);
   int best = 0, bs = -1000, ms = 1000;
 #pragma unroll
   for (int p = 0; p < NP; p++) {
-    const int c0 = LI(12 * p + s0[p]), c1 = LI(12 * p + s1[p]), sum = c0 + c1;
+    const int s0 = (int)((pw.open >> (8 * p)) & 0xfu), s1 = (int)((pw.open >> (8 * p + 4)) & 0xfu);
+    const int c0 = (int)(int8_t)DKW(12 * p + s0), c1 = (int)(int8_t)DKW(12 * p + s1), sum = c0 + c1;
     if (sum > bs) bs = sum, best = p;  // first argmax of revealed sums (skyjo.py:105-125)
     ms = sum < ms ? sum : ms;
     setb(L.off_sums + 2 * p, (uint32_t)sum), setb(L.off_sums + 2 * p + 1, (uint32_t)(sum >> 8));
     setb(L.off_hidden + p, 10);
 #pragma unroll
-    for (int j = 0; j < 3; j++) {  // vis row: 15 everywhere but the two open slots
+    for (int j = 0; j < 3; j++) {  // vis row: 15 everywhere but the two open slots; cards row-major (skyjo.py:63-65)
       uint32_t w = 0x0f0f0f0fu;
-      if ((s0[p] >> 2) == j) w = (w & ~(0xffu << ((s0[p] & 3) * 8))) | (((uint32_t)c0 & 0xffu) << ((s0[p] & 3) * 8));
-      if ((s1[p] >> 2) == j) w = (w & ~(0xffu << ((s1[p] & 3) * 8))) | (((uint32_t)c1 & 0xffu) << ((s1[p] & 3) * 8));
+      if ((s0 >> 2) == j) w = (w & ~(0xffu << ((s0 & 3) * 8))) | (((uint32_t)c0 & 0xffu) << ((s0 & 3) * 8));
+      if ((s1 >> 2) == j) w = (w & ~(0xffu << ((s1 & 3) * 8))) | (((uint32_t)c1 & 0xffu) << ((s1 & 3) * 8));
       rec[(L.off_vis >> 2) + 3 * p + j] = w;
-      rec[(L.off_cards >> 2) + 3 * p + j] = LW(3 * p + j);
+      rec[(L.off_cards >> 2) + 3 * p + j] = pack4(12 * p + 4 * j);
     }
     if (!L.indirect) {  // direct observation: open cards are counted too (skyjo.py:160,236-248)
 #pragma unroll
@@ -1322,7 +1455,7 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint8_t *lp, Rng
     uint32_t m = 0;
     for (int j = 0; j < 4; j++)
       if (4 * d + j < R - 1) m |= 0xffu << (8 * j);
-    uint32_t w = 3 * NP + d < (SK_NCARDS + 3) / 4 ? (LW(3 * NP + d) & m) : 0u;
+    uint32_t w = m ? (pack4(12 * NP + 4 * d) & m) : 0u;
     if (d == (SK_NCARDS - 1) / 4) w |= ((uint32_t)last & 0xffu) << (((SK_NCARDS - 1) & 3) * 8);
     rec[(L.off_pile >> 2) + d] = w;
   }
@@ -1335,6 +1468,7 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint8_t *lp, Rng
   for (int c = 0; c < 18 + 2; c++)
     if (4 * c < nwords) dst[(size_t)c * SK_TILE] = make_uint4(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]);
 }
+#undef DKW
 
 template <class Rng>
 __device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rng &r, uint32_t episode) {
@@ -1532,45 +1666,52 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
   uint4 *dst = P.spare + ((size_t)slot * P.tiles + g / SK_TILE) * P.L.chunks * SK_TILE + g % SK_TILE;
   bool mt_overrun = false;
   if (P.rng_mode == SKYJO_RNG_MT19937) {
-    // The stream advances in place; the old value of every regenerated element goes to the slot's undo log
-    // so that a mid-game reshuffle of the live episode (which numpy would have drawn BEFORE this deal) can
-    // roll the stream back and have the deal redone (reshuffle_dispatch).
+    // The stream advances in place; the position it had before this deal is kept with the slot so that a mid-game
+    // reshuffle of the live episode (which numpy would have drawn BEFORE this deal) can step the stream back
+    // (mt_untwist) and have the deal redone (reshuffle_dispatch).
     if (act) {
-      uint32_t *mt = P.mt + (size_t)g * 624, *undo = P.mt + ((size_t)(1 + slot) * G + g) * 624;
+      uint32_t *mt = P.mt + (size_t)g * 624;
       const int packed = P.mt_idx[g];
       P.mt_idx[(size_t)(1 + slot) * G + g] = packed;
       int generated;
       if (NP > 0) {
         MtChunkStream r;
-        r.open(mt, packed, undo);
+        r.open(mt, packed);
         STAMP(2);
-        deal_compact<NP>(P, lp, r, ep, dst);
+        deal_compact<NP>(P, lds_raw, lane, r, ep, dst);
         P.mt_idx[g] = r.close();
         generated = r.chunks_made * 16;
       } else {
         uint8_t *fp = lp + P.L.chunks * 1024;
         MtStream<64> r;
-        r.open(mt, packed, fp, undo);
+        r.open(mt, packed, fp);
         r.stp = &st;
         STAMP(2);
         deal_into_lds(P, lp, r, ep);
         P.mt_idx[g] = r.close();
         generated = r.wp - (((16 - ((packed >> 16) & 15)) & 15) + (packed >> 16));
       }
-      mt_overrun = generated > 624 - 64;  // the undo log is about to wrap: give this speculation up
-      if (mt_overrun) {
+      mt_overrun = generated > 624 - 64;  // close to a full turn of the state: positions alone could no longer tell
+      if (mt_overrun) {                   // how far a rollback has to go, so give this speculation up right here
         int k0 = (packed & 0xffff) + (packed >> 16);
         k0 = k0 >= 624 ? k0 - 624 : k0;
-        for (int k = 0; k < generated; k++, k0 = k0 + 1 == 624 ? 0 : k0 + 1) mt[k0] = undo[k0];
+        int k1 = k0 + generated;
+        k1 = k1 >= 624 ? k1 - 624 : k1;
+        mt_untwist(mt, k0, k1);
         P.mt_idx[g] = packed;
       }
       STAMP(3);
     }
   } else if (act) {
-    PhiloxStream r;
-    r.open(P.seeds[g] + 1, ep, 0u, 0u);
-    if (NP > 0) deal_compact<NP>(P, lp, r, ep, dst);
-    else deal_into_lds(P, lp, r, ep);
+    if (NP > 0) {
+      PhiloxChunkStream r;
+      r.open(P.seeds[g] + 1, ep, 0u, 0u);
+      deal_compact<NP>(P, lds_raw, lane, r, ep, dst);
+    } else {
+      PhiloxStream r;
+      r.open(P.seeds[g] + 1, ep, 0u, 0u);
+      deal_into_lds(P, lp, r, ep);
+    }
   }
   if (act) {
     if (NP == 0) tile_store(P, P.spare + (size_t)slot * P.tiles * P.L.chunks * SK_TILE, g / SK_TILE, g % SK_TILE, lp);
