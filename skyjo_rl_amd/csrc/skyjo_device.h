@@ -154,6 +154,19 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t v) {
   v ^= v >> 18;
   return v;
 }
+// The same with gfx950's three-input bit operation (truth table 0x78: a ^ (b & c), 0x96: a ^ b ^ c, 0xd8: c ? b : a)
+__device__ __forceinline__ uint32_t mt_temper3(uint32_t v) {
+  v ^= v >> 11;
+  v = __builtin_amdgcn_bitop3_b32(v, v << 7, 0x9d2c5680u, 0x78);
+  v = __builtin_amdgcn_bitop3_b32(v, v << 15, 0xefc60000u, 0x78);
+  v ^= v >> 18;
+  return v;
+}
+__device__ __forceinline__ uint32_t mt_twist3(uint32_t o0, uint32_t o1, uint32_t x) {  // new element from old[i], old[i+1], [i+397]
+  const uint32_t y = __builtin_amdgcn_bitop3_b32(o0, o1, 0x7fffffffu, 0xd8);
+  const uint32_t mag = (uint32_t)((int32_t)(o1 << 31) >> 31) & 0x9908b0dfu;
+  return __builtin_amdgcn_bitop3_b32(x, y >> 1, mag, 0x96);
+}
 template <int DEPTH>
 struct MtStream {
   uint32_t *mt;
@@ -1201,12 +1214,6 @@ struct MtChunkStream {
   __device__ __forceinline__ int close() const { return wrap(base + pos) | (((16 - pos) & 31) << 16); }
   __device__ __forceinline__ void issue() {
     const int c = gen;
-#ifdef SK_EXP_NOLOAD
-    for (int k = 0; k < 17; k++) o[k] = (uint32_t)(c + k) * 2654435761u ^ (uint32_t)(size_t)mt;
-    for (int k = 0; k < 16; k++) x[k] = (uint32_t)(c + k) * 40503u + (uint32_t)chunks_made;
-    issued = true;
-    return;
-#endif
     const uint4 *po = (const uint4 *)(mt + c);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1238,20 +1245,15 @@ struct MtChunkStream {
     const int c = gen;
     uint32_t v[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const uint32_t y = (o[k] & 0x80000000u) | (o[k + 1] & 0x7fffffffu);
-      v[k] = x[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-    }
+    for (int k = 0; k < 16; k++) v[k] = mt_twist3(o[k], o[k + 1], x[k]);
     base = c, pos = 0, chunks_made++;
     gen = c + 16 == 624 ? 0 : c + 16;
     issue();
 #pragma unroll
-    for (int k = 0; k < 16; k++) R[k] = mt_temper(v[k]);
-#ifndef SK_EXP_NOSTORE
+    for (int k = 0; k < 16; k++) R[k] = mt_temper3(v[k]);
     uint4 *pm = (uint4 *)(mt + c);
 #pragma unroll
     for (int k = 0; k < 4; k++) pm[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
-#endif
   }
 };
 
@@ -1285,12 +1287,16 @@ struct DeckWalk {
   uint32_t nxt_n;     // what n becomes when the current shuffle completes (R, then 0)
   uint32_t mask;      // rk_interval's mask for max = n - 1
 };
+#ifndef SK_DECK_BS
+#define SK_DECK_BS 2  // draws per batch (2: 96.6 us, 4: 99.9 us, 8: 102.2 us per dealing run at the headline size)
+#endif
 template <bool PRO, int NP, class Rng>
 __device__ __forceinline__ void deck_batch(Rng &r, const int s, uint32_t *lds_raw_base, const uint32_t dk, DeckWalk &w) {
   constexpr uint32_t R = SK_NCARDS - 12 * NP;
-  uint32_t pI[4], pJ[4];
+  constexpr int BS = SK_DECK_BS;
+  uint32_t pI[BS], pJ[BS];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < BS; k++) {
     const uint32_t v = r.R[s + k] & w.mask;
     const bool acc = PRO ? (v < w.n && s + k >= r.pos) : (v < w.n);
     pI[k] = w.pcur;
@@ -1301,32 +1307,25 @@ __device__ __forceinline__ void deck_batch(Rng &r, const int s, uint32_t *lds_ra
     w.n = t ? w.nxt_n : n2;
     w.pcur = t ? dk + ((SK_NCARDS - 1) << 8) : w.pcur + (d << 8);
     w.pb = t ? dk + ((12 * NP) << 8) : w.pb;
-    w.nxt_n = t ? 0u : w.nxt_n;
     r.pos = t ? s + k + 1 : r.pos;  // (a lane that is still shuffling after the block gets pos = 16 from the caller)
-    w.mask = 0xffffffffu >> (__clz((int)(w.n - 1u)) & 31);
+    w.mask = 0xffffffffu >> __builtin_clz(w.n - 1u);  // (n - 1 is never 0)
   }
-  uint32_t cI[4], cJ[4];
+  w.nxt_n = w.pb == dk ? R : 0u;  // (a batch never holds two completions: the rest takes > 100 draws)
+  uint32_t cI[BS], cJ[BS];
 #pragma unroll
-  for (int k = 0; k < 4; k++) cI[k] = DK_AT(pI[k]), cJ[k] = DK_AT(pJ[k]);
-#ifdef SK_EXP_NODECK
-  for (int k = 0; k < 4; k++) cI[k] = pI[k], cJ[k] = pJ[k];
-#endif
+  for (int k = 0; k < BS; k++) cI[k] = DK_AT(pI[k]), cJ[k] = DK_AT(pJ[k]);
   // What step k finds at its two positions is what the batch's earlier steps left there.  Only an earlier step's
   // j-position can be met again: its i-position lies above everything that follows (or, for an unused draw, is
   // its j-position).  The latest writer wins, hence ascending m.
 #pragma unroll
-  for (int k = 1; k < 4; k++)
+  for (int k = 1; k < BS; k++)
 #pragma unroll
     for (int m = 0; m < k; m++) {
       cI[k] = pJ[m] == pI[k] ? cI[m] : cI[k];
       cJ[k] = pJ[m] == pJ[k] ? cI[m] : cJ[k];
     }
-#ifndef SK_EXP_NODECK
 #pragma unroll
-  for (int k = 0; k < 4; k++) DK_AT(pI[k]) = cJ[k], DK_AT(pJ[k]) = cI[k];
-#else
-  if (cI[3] + cJ[3] + cI[2] + cJ[2] + cI[1] + cJ[1] + cI[0] + cJ[0] == 0x12345u) DK_AT(pI[0]) = 0;
-#endif
+  for (int k = 0; k < BS; k++) DK_AT(pI[k]) = cJ[k], DK_AT(pJ[k]) = cI[k];
 }
 
 // _reset_card_mask (skyjo.py:96-103): choice(12, 2, replace=False) == permutation(12)[:2] per player, i.e. a full
@@ -1353,11 +1352,18 @@ __device__ __forceinline__ void perm_batch(Rng &r, const int s, PermWalk &w) {
     w.pm = t ? 0xBA9876543210ull : w.pm;
     w.n = t ? (w.sh == 8u * NP ? 0u : 12u) : n2;
     r.pos = t ? s + k + 1 : r.pos;
-    w.mask = 0xffffffffu >> (__clz((int)(w.n - 1u)) & 31);
+    w.mask = 0xffffffffu >> __builtin_clz(w.n - 1u);  // (n - 1 is never 0)
   }
 }
 
 #define SK_FOUR_BATCHES(CALL) CALL(0) CALL(4) CALL(8) CALL(12)
+#if SK_DECK_BS == 4
+#define SK_DECK_BATCHES(CALL) CALL(0) CALL(4) CALL(8) CALL(12)
+#elif SK_DECK_BS == 2
+#define SK_DECK_BATCHES(CALL) CALL(0) CALL(2) CALL(4) CALL(6) CALL(8) CALL(10) CALL(12) CALL(14)
+#elif SK_DECK_BS == 8
+#define SK_DECK_BATCHES(CALL) CALL(0) CALL(8)
+#endif
 
 // Compact deal (fixed player count NP): only the deck lives in LDS; the game record is assembled in registers.
 // RNG order: shuffle(150) -> shuffle(rest) -> NP x permutation(12)[:2].
@@ -1375,7 +1381,7 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_ra
     w.pb = dk, w.pcur = dk + ((SK_NCARDS - 1) << 8), w.n = SK_NCARDS, w.nxt_n = R, w.mask = 0xffu;
     if (r.pos < 16) {
 #define SK_CALL(s) deck_batch<true, NP>(r, s, lds_raw_base, dk, w);
-      SK_FOUR_BATCHES(SK_CALL)
+      SK_DECK_BATCHES(SK_CALL)
 #undef SK_CALL
       r.pos = w.n ? 16 : r.pos;
     }
@@ -1383,7 +1389,7 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_ra
     while (w.n) {
       r.refill();
 #define SK_CALL(s) deck_batch<false, NP>(r, s, lds_raw_base, dk, w);
-      SK_FOUR_BATCHES(SK_CALL)
+      SK_DECK_BATCHES(SK_CALL)
 #undef SK_CALL
       r.pos = w.n ? 16 : r.pos;
     }
