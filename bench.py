@@ -26,7 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
-CHUNK = 16             # lockstep iterations per kernel launch (= kMaxRolloutChunk in skyjo_capi.hip)
+CHUNK = int(os.environ.get("SKYJO_BENCH_CHUNK", "32"))  # lockstep iterations per kernel launch (<= kMaxRolloutChunk in skyjo_capi.hip)
 
 
 def algorithmic_bytes_per_launch(B, N, D, iters, actions=True):

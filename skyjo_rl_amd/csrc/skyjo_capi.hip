@@ -28,10 +28,10 @@ int fail(int code, const std::string &msg) {
       return fail(SKYJO_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));             \
   } while (0)
 
-constexpr int kMaxRolloutChunk = 16;
-constexpr int kDealEveryIters = 64;  // default: lockstep iterations between two k_deal launches (the bank is 2 deep
-                                     // and no episode of two or more players is shorter than 41 steps)  // iterations per launch: shorter than any episode, so a game
-                                      // never needs two fresh deals inside one launch
+constexpr int kMaxRolloutChunk = 64;  // lockstep iterations per k_step launch (the tile stays in LDS for a whole launch)
+constexpr int kDealEveryIters = 64;   // default: lockstep iterations between two dealing runs; a game's bank of
+                                      // SK_BANK episodes outlasts that (no episode of two or more players is shorter
+                                      // than 41 steps), and a bank that does run dry deals in place (deal_inline)
 
 }  // namespace
 
