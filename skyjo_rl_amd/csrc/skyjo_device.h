@@ -586,16 +586,30 @@ __device__ __forceinline__ uint32_t pack12(uint32_t a, uint32_t b, uint32_t c) {
          (((c * 0x00204081u >> 21) & 0xfu) << 8);
 }
 
+// What an observer of the table needs from the expected player's `vis` row, kept in registers from the record of
+// one iteration to the policy pick and the legality test of the next (same player, same row): the row itself and,
+// per slot, "not refunded" (players_masked != 0) and "hidden" (players_masked == 2) as 0/1 bytes
+// (skyjo.py:201-224).
+struct ObsRegs {
+  uint32_t q0, q1, q2, nz0, nz1, nz2, hd0, hd1, hd2;
+};
+__device__ __forceinline__ void obs_load(const SkParams &P, uint8_t *lp, int q, ObsRegs &o) {
+  const int vq = (P.L.off_vis + 12 * q) >> 2;
+  o.q0 = LW(vq), o.q1 = LW(vq + 1), o.q2 = LW(vq + 2);
+  o.nz0 = swar_nonzero01(o.q0 ^ 0xf2f2f2f2u);  // vis != -14  <=> players_masked != 0
+  o.nz1 = swar_nonzero01(o.q1 ^ 0xf2f2f2f2u);
+  o.nz2 = swar_nonzero01(o.q2 ^ 0xf2f2f2f2u);
+  o.hd0 = swar_nonzero01(o.q0 ^ 0x0f0f0f0fu) ^ 0x01010101u;  // vis == 15 <=> players_masked == 2
+  o.hd1 = swar_nonzero01(o.q1 ^ 0x0f0f0f0fu) ^ 0x01010101u;
+  o.hd2 = swar_nonzero01(o.q2 ^ 0x0f0f0f0fu) ^ 0x01010101u;
+}
+
 // uniform choice over the legal actions == policy_ra's p = mask / sum(mask)
 // (rlskyjo/models/random_admissible_policy.py:26-28); word = Philox4x32-10 output for this
 // (game, iteration), k = mulhi(word, n_legal), action = k-th legal action in ascending order.
-__device__ __forceinline__ int policy_pick(int phase, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t word) {
+__device__ __forceinline__ int policy_pick(int phase, const ObsRegs &o, uint32_t word) {
   if (phase == 0) return 24 + (int)__umulhi(word, 2u);
-  uint32_t legal = pack12(swar_nonzero01(q0 ^ 0xf2f2f2f2u), swar_nonzero01(q1 ^ 0xf2f2f2f2u),
-                          swar_nonzero01(q2 ^ 0xf2f2f2f2u)) |
-                   (pack12(swar_nonzero01(q0 ^ 0x0f0f0f0fu) ^ 0x01010101u, swar_nonzero01(q1 ^ 0x0f0f0f0fu) ^ 0x01010101u,
-                           swar_nonzero01(q2 ^ 0x0f0f0f0fu) ^ 0x01010101u)
-                    << 12);
+  uint32_t legal = pack12(o.nz0, o.nz1, o.nz2) | (pack12(o.hd0, o.hd1, o.hd2) << 12);
   const int n = __popc(legal);
   if (n == 0) return 24;
   int k = (int)__umulhi(word, (uint32_t)n), pos = 0;
@@ -786,23 +800,14 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
 // order (direct, skyjo.py:279-302).
 // ------------------------------------------------------------------------------------------
 template <bool INDIRECT>
-__device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, const HdrRegs &h, int q, uint8_t *out) {
+__device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, const HdrRegs &h, const ObsRegs &ob, uint8_t *out) {
   const int phase = h.w0 & 0xff;
-  const int vq = (P.L.off_vis + 12 * q) >> 2;
-  const uint32_t q0 = LW(vq), q1 = LW(vq + 1), q2 = LW(vq + 2);
+  const uint32_t q0 = ob.q0, q1 = ob.q1, q2 = ob.q2;
   uint32_t m[8];
   {
-    m[0] = m[1] = m[2] = m[3] = m[4] = m[5] = 0u;
-    {  // (computed in both phases and masked: a branch on the phase measured 2 us slower per launch)
-      m[0] = swar_nonzero01(q0 ^ 0xf2f2f2f2u);  // vis != -14  <=> players_masked != 0
-      m[1] = swar_nonzero01(q1 ^ 0xf2f2f2f2u);
-      m[2] = swar_nonzero01(q2 ^ 0xf2f2f2f2u);
-      m[3] = swar_nonzero01(q0 ^ 0x0f0f0f0fu) ^ 0x01010101u;  // vis == 15 <=> players_masked == 2
-      m[4] = swar_nonzero01(q1 ^ 0x0f0f0f0fu) ^ 0x01010101u;
-      m[5] = swar_nonzero01(q2 ^ 0x0f0f0f0fu) ^ 0x01010101u;
-      const uint32_t pm = phase ? 0xffffffffu : 0u;
-      m[0] &= pm, m[1] &= pm, m[2] &= pm, m[3] &= pm, m[4] &= pm, m[5] &= pm;
-    }
+    // (computed in both phases and masked: a branch on the phase measured 2 us slower per launch)
+    const uint32_t pm = phase ? 0xffffffffu : 0u;
+    m[0] = ob.nz0 & pm, m[1] = ob.nz1 & pm, m[2] = ob.nz2 & pm, m[3] = ob.hd0 & pm, m[4] = ob.hd1 & pm, m[5] = ob.hd2 & pm;
     m[6] = (phase ? 0u : 0x0101u) | (((h.w0 >> 8) & 0xffu) << 16) | ((uint32_t)phase << 24);
     m[7] = (((h.w0 >> 16) & F_DONE) ? 1u : 0u) | ((h.w0 >> 24) << 8) | ((h.w2 & 0xffffu) << 16);
   }
@@ -949,6 +954,8 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   LaneCounters cnt;
   uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
   const uint64_t gid = P.game_id0 + (uint64_t)g;
+  ObsRegs ob;
+  if (valid) obs_load(P, lp, (h.w0 >> 8) & 0xff, ob);
   for (int it = 0; it < iters; it++) {
     const uint64_t iter = iter0 + (uint64_t)it;
     if (POLICY && (it == 0 || (iter & 3) == 0))
@@ -961,12 +968,11 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
       SpareRegs<CH> sp;
       if (NP > 0 && over && P.auto_reset) spare_issue<CH>(P, lp, tile, lane, g, sp);  // lands after the live games' step
       if (!over) {
-        const int vw = (P.L.off_vis + 12 * (int)((h.w0 >> 8) & 0xff)) >> 2;
-        const uint32_t v0 = LW(vw), v1 = LW(vw + 1), v2 = LW(vw + 2);
+        const uint32_t v0 = ob.q0, v1 = ob.q1, v2 = ob.q2;  // the acting player's row, read for the previous record
         STAMP(2);
         if (POLICY) {
           const uint32_t sel = (uint32_t)(iter & 3);
-          a = policy_pick(h.w0 & 0xff, v0, v1, v2, sel == 0 ? r0 : sel == 1 ? r1 : sel == 2 ? r2 : r3);
+          a = policy_pick(h.w0 & 0xff, ob, sel == 0 ? r0 : sel == 1 ? r1 : sel == 2 ? r2 : r3);
         } else {
           a = actions[g];
         }
@@ -995,8 +1001,8 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
         }
         STAMP(1);
       }
-      if (rec_out)
-        emit_record<INDIRECT>(P, lp, h, (h.w0 >> 8) & 0xff, rec_out + ((size_t)it * P.B + g) * (size_t)P.L.rec_bytes);
+      obs_load(P, lp, (h.w0 >> 8) & 0xff, ob);  // one read of the row serves this record and the next iteration's turn
+      if (rec_out) emit_record<INDIRECT>(P, lp, h, ob, rec_out + ((size_t)it * P.B + g) * (size_t)P.L.rec_bytes);
       if (act_out) act_out[(size_t)it * P.B + g] = a;
 #ifdef SK_STAMPS_FINE
       STAMP(7);
@@ -1046,7 +1052,9 @@ __global__ __launch_bounds__(SK_TILE) void k_observe(SkParams P, const int32_t *
   HDR_LOAD(h);
   int q = players ? players[g] : LB(H_PLAYER);
   q = q < 0 ? 0 : (q >= P.L.N ? P.L.N - 1 : q);
-  emit_record<INDIRECT>(P, lp, h, q, rec_out + (size_t)g * P.L.rec_bytes);
+  ObsRegs ob;
+  obs_load(P, lp, q, ob);
+  emit_record<INDIRECT>(P, lp, h, ob, rec_out + (size_t)g * P.L.rec_bytes);
 }
 
 // SkyjoGame.reset for the masked games: take the pre-dealt episode.
@@ -1065,7 +1073,11 @@ __global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *ma
   }
   HdrRegs h;
   HDR_LOAD(h);
-  if (rec_out) emit_record<INDIRECT>(P, lp, h, LB(H_PLAYER), rec_out + (size_t)g * P.L.rec_bytes);
+  if (rec_out) {
+    ObsRegs ob;
+    obs_load(P, lp, LB(H_PLAYER), ob);
+    emit_record<INDIRECT>(P, lp, h, ob, rec_out + (size_t)g * P.L.rec_bytes);
+  }
   if (want) tile_store(P, P.state, tile, lane, lp);
   const unsigned long long wb = __ballot(want);
   if (want && lane == __ffsll((long long)wb) - 1) P.tile_counters[(size_t)tile * 8 + 3] += __popcll(wb);
