@@ -7,13 +7,14 @@ from skyjo_rl_amd import SkyjoVecEnv, _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 eng = SkyjoVecEnv(B, num_players=3)
 eng.seed(None, 0)
-rec = eng.new_records(16); act = torch.empty((16, B), dtype=torch.int32, device="cuda")
+ITERS = 32
+rec = eng.new_records(ITERS); act = torch.empty((ITERS, B), dtype=torch.int32, device="cuda")
 if len(sys.argv) > 2 and sys.argv[2] == "norec": rec = act = None
-for _ in range(20): eng.rollout(16, 1, records=rec, actions=act)
+for _ in range(20): eng.rollout(ITERS, 1, records=rec, actions=act)
 torch.cuda.synchronize()
 out = np.zeros(16, dtype=np.uint64)
 _lib.check(eng._L.skyjo_vec_debug_stamps(eng._h, out.ctypes.data_as(C.c_void_p)))
-for _ in range(10): eng.rollout(16, 1, records=rec, actions=act)
+for _ in range(10): eng.rollout(ITERS, 1, records=rec, actions=act)
 torch.cuda.synchronize()
 _lib.check(eng._L.skyjo_vec_debug_stamps(eng._h, out.ctypes.data_as(C.c_void_p)))
 names = ["tile_load", "reset commit", "top: philox, spare issue, vis read (+pick)", "draw path (+finish)", "place: legality", "place A: reads", "place B: update (+draw join)", "emit+stores (+tile_store)"] if os.environ.get("FINE") else ["tile_load", "philox+reset path", "vis row load", "policy_pick", "apply: legality+draw(+finish)", "apply: place", "emit+stores", "tile_store+counters"]
@@ -23,5 +24,5 @@ for n, v in zip(dn, out[8:]):
     print("deal %-25s %6.1f%%  %9.0f cycles/wave/launch" % (n, 100 * v / max(dt, 1), v / dwaves))
 tot = float(out[:8].sum()); waves = (B + 63) // 64 * 10
 for n, v in zip(names, out[:8]):
-    print("%-30s %6.1f%%  %9.0f cycles/wave/launch  %8.0f /iter" % (n, 100 * v / tot, v / waves, v / waves / 16))
+    print("%-30s %6.1f%%  %9.0f cycles/wave/launch  %8.0f /iter" % (n, 100 * v / tot, v / waves, v / waves / ITERS))
 print("total cycles/wave/launch %.0f" % (tot / waves))
