@@ -783,7 +783,10 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
   }
   LSH(P.L.off_sums + 2 * p) = (int16_t)sum;
   LB(P.L.off_hidden + p) = (uint8_t)hid;
-  LH(P.L.off_placed + 2 * p)++;
+  {  // num_placed[p]++ (skyjo.py:424) as a fire-and-forget add on the dword that holds the u16: no read, no wait
+    const int b = P.L.off_placed + 2 * p;
+    __hip_atomic_fetch_add((uint32_t *)(lp + ((b >> 2) << 8)), 1u << ((b & 2) * 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
   const int ms = sum < oms ? sum : oms, mh = hid < omh ? hid : omh;
   LB(H_MINSUM) = (uint8_t)(int8_t)(ms < 127 ? ms : 127);
   LB(H_MINHID) = (uint8_t)mh;
