@@ -33,7 +33,7 @@
 #define H_MINHID 17   // min_p hidden_count_p
 #define H_HIST 18     // u8[15] bincount of values -2..12 (updated with dword LDS atomics)
 #define H_FINISHER 33
-#define H_BANK 34      // which of the game's two pre-dealt episodes is taken next (mirrors SkParams.bank_head)
+#define H_BANK 34      // which of the game's SK_BANK pre-dealt episodes is taken next (mirrors SkParams.bank_head)
 #define H_END 36
 
 #define F_TERMINATED 1  // is_terminated (skyjo.py:54)
