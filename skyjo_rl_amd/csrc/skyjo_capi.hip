@@ -106,7 +106,7 @@ int start_deals(skyjo_vec *h, hipStream_t s) {
   if (h->deal_tag == 0) h->deal_tag = 1;
   h->P.deal_tag = h->deal_tag;
   // (the list's counter was cleared by the previous run's publish step)
-  hipLaunchKernelGGL(k_scan, dim3((h->P.B + 255) / 256), dim3(256), 0, s, h->P, h->list_sel);
+  hipLaunchKernelGGL(k_scan, dim3((h->P.B + SK_SCAN_BLOCK - 1) / SK_SCAN_BLOCK), dim3(SK_SCAN_BLOCK), 0, s, h->P, h->list_sel);
   HIPCHK(hipGetLastError());
   hipStream_t ds = s;
   if (h->overlap) {

@@ -395,7 +395,9 @@ __device__ __forceinline__ bool wait_deal_done(const SkParams &P, int g) {
 // backwards from the newest element, S[i+397] and S[i+1] are exactly what they were when i was made, so
 // twist(y) = new[i] ^ S[i+397]; bit 31 of twist(y) tells whether y was odd (the magic constant has it set, y >> 1 has
 // not), which gives y back: its top bit is old S[i]'s, its low 31 bits are old S[i+1]'s.  The low 31 bits of the
-// oldest element undone come from the y of the element before it, which is still in place.
+// OLDEST element undone stay unknown (zero) - and are never looked at again: the only thing they ever feed is the
+// element before it, which was made earlier and is still in place (tests/test_untwist_identity.py shows the stream
+// continuing identically; undoing the deal before this one restores them first thing).
 __device__ __forceinline__ uint32_t mt_untwist_y(const uint32_t *mt, int i) {
   uint32_t t = mt[i] ^ mt[i + 397 >= 624 ? i + 397 - 624 : i + 397];
   const uint32_t odd = t >> 31;
@@ -403,7 +405,6 @@ __device__ __forceinline__ uint32_t mt_untwist_y(const uint32_t *mt, int i) {
   return (t << 1) | odd;
 }
 __device__ __forceinline__ void mt_untwist(uint32_t *mt, int from, int to) {  // undo elements [from, to) in stream order
-  if (from == to) return;
   for (int i = to; i != from;) {
     const int nx = i == 624 ? 0 : i;  // (to may be given as 624)
     i = nx == 0 ? 623 : nx - 1;
@@ -412,8 +413,6 @@ __device__ __forceinline__ void mt_untwist(uint32_t *mt, int from, int to) {  //
     mt[ip1] = (mt[ip1] & 0x80000000u) | (y & 0x7fffffffu);
     mt[i] = y & 0x80000000u;
   }
-  const uint32_t y = mt_untwist_y(mt, from == 0 ? 623 : from - 1);
-  mt[from] = (mt[from] & 0x80000000u) | (y & 0x7fffffffu);
 }
 
 // Take back the deal that filled bank slot `slot`: the stream returns to where it stood before that deal.
@@ -1602,13 +1601,17 @@ __device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint
 //   k_publish (caller's stream, after k_deal has finished) marks the new slots ready and clears busy.
 // All bank bookkeeping (head, ready flags, busy, cancel) is only ever written on the caller's stream.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scan(SkParams P, int list_sel) {
+#define SK_SCAN_BLOCK 1024
+__global__ __launch_bounds__(SK_SCAN_BLOCK) void k_scan(SkParams P, int list_sel) {
+  // One atomic per 1024 games reserves the block's stretch of the work list (same-address atomics serialise at
+  // ~12 ns each: one per wavefront made this kernel 13 us long, two thirds of it queueing on deal_count).
+  __shared__ uint32_t wave_need[SK_SCAN_BLOCK / 64], block_first;
   const size_t G = (size_t)P.tiles * SK_TILE;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int32_t *list = P.deal_list + (size_t)list_sel * G;
   uint32_t *eps = P.deal_ep + (size_t)list_sel * G;
-  for (int base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; base < P.B; base += gridDim.x * blockDim.x) {
-    const int g = base + lane;
+  for (int base = blockIdx.x * SK_SCAN_BLOCK; base < P.B; base += gridDim.x * SK_SCAN_BLOCK) {
+    const int g = base + (int)threadIdx.x;
     bool need = false;
     int slot = 0, r = 0;
     uint32_t consumed = 0;
@@ -1633,18 +1636,26 @@ __global__ __launch_bounds__(256) void k_scan(SkParams P, int list_sel) {
       slot = (head + r) % SK_BANK;  // slots fill in stream order
     }
     const unsigned long long b = __ballot(need);
-    if (b) {
-      uint32_t first = 0;
-      if (lane == 0) first = atomicAdd(&P.deal_count[list_sel], (uint32_t)__popcll(b));
-      first = __shfl(first, 0, 64);
-      if (need) {
-        const uint32_t pos = first + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-        list[pos] = g;
-        eps[pos] = consumed + (uint32_t)r;
-        P.busy[g] = (uint8_t)(1 + slot);
-        P.cancel[g] = 0;
+    if (lane == 0) wave_need[wave] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t total = 0;
+      for (int w = 0; w < SK_SCAN_BLOCK / 64; w++) {
+        const uint32_t n = wave_need[w];
+        wave_need[w] = total;  // -> offset of the wavefront inside the block's stretch
+        total += n;
       }
+      block_first = total ? atomicAdd(&P.deal_count[list_sel], total) : 0u;
     }
+    __syncthreads();
+    if (need) {
+      const uint32_t pos = block_first + wave_need[wave] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+      list[pos] = g;
+      eps[pos] = consumed + (uint32_t)r;
+      P.busy[g] = (uint8_t)(1 + slot);
+      P.cancel[g] = 0;
+    }
+    __syncthreads();  // (the shared words are reused by the next stretch)
   }
 }
 
