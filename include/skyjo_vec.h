@@ -196,6 +196,22 @@ int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
 #define SKYJO_OPT_OVERLAP 2
 int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value);
 
+/* Caller piece of config 5: the masking and sampling step of the action-mask policy model,
+ * rlskyjo/models/action_mask_model.py:58-74 -  masked = logits + clamp(log(action_mask), min=FLOAT_MIN)  - followed
+ * by RLlib's categorical draw from softmax(masked), fused into one pass over the records the engine has just
+ * written (the mask bytes are read in place, offset mask_offset of each record).
+ *   logits     float32 [n][26]  the policy net's outputs (device)
+ *   records    [n][record_bytes] as written by step / reset / observe / rollout (device)
+ *   seed, ticket   the uniform of game i is word 0 of Philox4x32-10(counter = (ticket, game_id0 + i, 0x53414D50),
+ *              key = seed): the same (seed, ticket) reproduces the same draws; advance ticket once per step
+ *   no_masking != 0: the mask is ignored (action_mask_model.py:53-56,66-67)
+ *   actions_out int32 [n]; logp_out float32 [n] (log-probability of the drawn action) or NULL;
+ *   uniform_out float32 [n] (the uniforms in [0, 1), for tests) or NULL.
+ * Arithmetic is float32: probabilities agree with torch.softmax to 1e-6 (tests/test_gpu_sampler.py). */
+int skyjo_vec_sample_actions(skyjo_vec *h, const void *records, const float *logits, int64_t n, uint64_t seed,
+                             uint64_t ticket, int32_t no_masking, int32_t *actions_out, float *logp_out,
+                             float *uniform_out, void *stream);
+
 /* host-pointer conveniences for small batches (single-game AEC view): synchronous */
 int skyjo_vec_step_host(skyjo_vec *h, const int32_t *actions_host, void *records_out_host);
 int skyjo_vec_observe_host(skyjo_vec *h, const int32_t *players_host, void *records_out_host);

@@ -63,6 +63,7 @@ SIGNATURES = {
     "skyjo_vec_rollout": (C.c_int, [VP, I32, U64, VP, VP, VP]),
     "skyjo_vec_observe": (C.c_int, [VP, VP, VP, VP]),
     "skyjo_vec_unpack": (C.c_int, [VP, VP, I64, VP, VP, VP, VP, VP, VP, VP]),
+    "skyjo_vec_sample_actions": (C.c_int, [VP, VP, VP, I64, U64, U64, I32, VP, VP, VP, VP]),
     "skyjo_vec_rewards_ptr": (VP, [VP]),
     "skyjo_vec_scores_ptr": (VP, [VP]),
     "skyjo_vec_done_ptr": (VP, [VP]),

@@ -5,7 +5,9 @@ default fully connected net (two tanh layers of 256 units, separate value branch
 ``obs["observations"]``, and ``logits + clamp(log(action_mask), min=FLOAT_MIN)`` as in :58-74.  It
 consumes the zero-copy views of the engine's record tensor directly on the GPU (``SkyjoVecEnv.split``),
 so a PPO-style rollout never leaves the device.  This is caller code, not part of the accelerated
-path; MFMA work (the three small GEMMs) is left to PyTorch-ROCm / hipBLASLt.
+path; MFMA work (the three small GEMMs) is left to PyTorch-ROCm / hipBLASLt.  The masking + categorical
+draw has a fused HIP form behind the C ABI (``skyjo_vec_sample_actions``, ``sample_actions_fused`` below);
+``forward`` / ``sample_actions`` are the plain-torch statement of the same arithmetic and its test reference.
 """
 import torch
 from torch import nn
@@ -48,3 +50,14 @@ def sample_actions(model, obs, generator=None):
     """Categorical sample from the masked logits -> int32 actions for SkyjoVecEnv.step."""
     probs = torch.softmax(model(obs), dim=-1)
     return torch.multinomial(probs, 1, generator=generator).squeeze(-1).to(torch.int32)
+
+
+@torch.no_grad()
+def sample_actions_fused(model, env, records, seed=0, ticket=0, logp=None):
+    """The same draw with the masking, softmax and sampling fused into one HIP pass over the engine's records
+    (``SkyjoVecEnv.sample_actions``): only the policy net's three GEMMs run in torch."""
+    v = env.split(records)
+    x = v.observations.to(torch.float32)
+    model._last_obs = x
+    logits = model.policy(x)
+    return env.sample_actions(logits, records, seed=seed, ticket=ticket, no_masking=model.no_masking, logp=logp)

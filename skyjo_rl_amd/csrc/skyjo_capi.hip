@@ -372,6 +372,19 @@ const double *skyjo_vec_rewards_ptr(const skyjo_vec *h) { return h ? h->P.reward
 const double *skyjo_vec_scores_ptr(const skyjo_vec *h) { return h ? h->P.scores : nullptr; }
 const uint8_t *skyjo_vec_done_ptr(const skyjo_vec *h) { return h ? h->P.done : nullptr; }
 
+int skyjo_vec_sample_actions(skyjo_vec *h, const void *records, const float *logits, int64_t n, uint64_t seed,
+                             uint64_t ticket, int32_t no_masking, int32_t *actions_out, float *logp_out,
+                             float *uniform_out, void *stream) {
+  if (!h || !records || !logits || !actions_out || n < 0) return fail(SKYJO_E_INVALID, "null argument");
+  if (n == 0) return SKYJO_OK;
+  const int64_t blocks = (n + SK_SAMPLE_BLOCK - 1) / SK_SAMPLE_BLOCK;
+  hipLaunchKernelGGL(k_sample, dim3((unsigned)blocks), dim3(SK_SAMPLE_BLOCK), 0, (hipStream_t)stream, h->P.L,
+                     (const uint8_t *)records, logits, (long long)n, seed, ticket, h->P.game_id0, (int)no_masking,
+                     actions_out, logp_out, uniform_out);
+  HIPCHK(hipGetLastError());
+  return SKYJO_OK;
+}
+
 int skyjo_vec_get_counters(skyjo_vec *h, skyjo_vec_counters *out, void *stream) {
   if (!h || !out) return fail(SKYJO_E_INVALID, "null argument");
   static_assert(sizeof(SkCounters) == sizeof(skyjo_vec_counters), "counter structs must match");

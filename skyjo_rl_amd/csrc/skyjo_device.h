@@ -1794,6 +1794,73 @@ __global__ void k_reduce_stats(SkParams P) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Config 5 caller piece: TorchActionMaskModel.forward's masking (rlskyjo/models/action_mask_model.py:58-74) and the
+// categorical draw, one lane per game.  256 games per block: their 256 x 26 logits are one contiguous 26.6 KB
+// stretch that is copied to LDS with coalesced 16-byte loads; a lane then walks its own row (stride 26 words:
+// two lanes per bank).  The mask bytes come straight out of the engine's records.
+// ------------------------------------------------------------------------------------------
+#define SK_SAMPLE_BLOCK 256
+__global__ __launch_bounds__(SK_SAMPLE_BLOCK) void k_sample(SkLayout L, const uint8_t *rec, const float *logits, long long n,
+                                                            uint64_t seed, uint64_t ticket, uint64_t game_id0, int no_masking,
+                                                            int32_t *actions, float *logp, float *uniform) {
+  __shared__ float rows[SK_SAMPLE_BLOCK * SKYJO_NUM_ACTIONS];
+  const long long g0 = (long long)blockIdx.x * SK_SAMPLE_BLOCK;
+  const int nb = (int)(n - g0 < SK_SAMPLE_BLOCK ? n - g0 : SK_SAMPLE_BLOCK);
+  const float *src = logits + g0 * SKYJO_NUM_ACTIONS;  // (256 * 26 * 4 bytes per block: 16-byte aligned)
+  const int words = nb * SKYJO_NUM_ACTIONS;
+  for (int w = threadIdx.x * 4; w < words; w += SK_SAMPLE_BLOCK * 4) {
+    if (w + 4 <= words) {
+      const float4 v = *(const float4 *)(src + w);
+      rows[w] = v.x, rows[w + 1] = v.y, rows[w + 2] = v.z, rows[w + 3] = v.w;
+    } else {
+      for (int k = w; k < words; k++) rows[k] = src[k];
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x >= nb) return;
+  const long long g = g0 + threadIdx.x;
+  const uint8_t *r = rec + g * L.rec_bytes + L.Dp;  // 26 mask bytes, 4-byte aligned
+  uint32_t mw[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) mw[k] = ((const uint32_t *)r)[k];
+  const float *row = rows + threadIdx.x * SKYJO_NUM_ACTIONS;
+  const float FLOAT_MIN = -3.4028234663852886e38f;  // torch.finfo(float32).min == ray's FLOAT_MIN
+  float m[SKYJO_NUM_ACTIONS], mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < SKYJO_NUM_ACTIONS; k++) {
+    const bool on = no_masking || ((mw[k >> 2] >> ((k & 3) * 8)) & 0xffu) != 0;
+    m[k] = on ? row[k] : row[k] + FLOAT_MIN;  // log(1) = 0, clamp(log(0)) = FLOAT_MIN
+    mx = fmaxf(mx, m[k]);
+  }
+  float e[SKYJO_NUM_ACTIONS], sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < SKYJO_NUM_ACTIONS; k++) e[k] = __expf(m[k] - mx), sum += e[k];
+  uint32_t u0, u1, u2, u3;
+  const uint64_t gid = game_id0 + (uint64_t)g;
+  philox4x32_10((uint32_t)ticket, (uint32_t)(ticket >> 32), (uint32_t)gid, 0x53414D50u ^ (uint32_t)(gid >> 32), (uint32_t)seed,
+                (uint32_t)(seed >> 32), u0, u1, u2, u3);
+  const float u = (float)(u0 >> 8) * (1.0f / 16777216.0f);  // 24 bits -> [0, 1)
+  const float target = u * sum;
+  float acc = 0.f;
+  int a = -1, last_on = 0;
+#pragma unroll
+  for (int k = 0; k < SKYJO_NUM_ACTIONS; k++) {
+    acc += e[k];
+    last_on = e[k] > 0.f ? k : last_on;
+    a = (a < 0 && acc > target) ? k : a;
+  }
+  a = a < 0 ? last_on : a;  // (rounding at the very top of the distribution)
+  actions[g] = a;
+  if (logp) {
+    float ma = m[0];
+#pragma unroll
+    for (int k = 1; k < SKYJO_NUM_ACTIONS; k++) ma = a == k ? m[k] : ma;
+    logp[g] = (ma - mx) - __logf(sum);
+  }
+  if (uniform) uniform[g] = u;
+}
+
 // records -> the reference's dense arrays (obs int8[n][D], mask int8[n][26], ...)
 __global__ void k_unpack(SkLayout L, const uint8_t *rec, long long n, int8_t *obs, int8_t *mask, uint8_t *agent,
                          uint8_t *phase, uint8_t *done, uint8_t *status) {

@@ -154,6 +154,22 @@ class SkyjoVecEnv:
                                             C.c_void_p(mask.data_ptr()), None, None, None, None, self._stream()))
         return obs, mask
 
+    def sample_actions(self, logits, records, seed=0, ticket=0, no_masking=False, actions=None, logp=None, uniform=None):
+        """Masked categorical draw of config 5 (rlskyjo/models/action_mask_model.py:58-74 + the sampling RLlib does on
+        the masked logits) fused on the GPU: ``logits`` float32 [n, 26]; the action mask is read in place from
+        ``records``.  Returns int32 actions; ``logp`` / ``uniform`` (float32 [n]) are filled when given."""
+        torch = self._torch()
+        n = records.numel() // self.record_bytes
+        assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.numel() == n * 26
+        assert records.is_contiguous()
+        if actions is None:
+            actions = torch.empty((n,), dtype=torch.int32, device=self._dev())
+        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(self._L.skyjo_vec_sample_actions(self._h, vp(records), vp(logits), n, int(seed), int(ticket),
+                                                    1 if no_masking else 0, vp(actions), vp(logp), vp(uniform),
+                                                    self._stream()))
+        return actions
+
     def rewards_tensor(self):
         torch = self._torch()
         out = torch.empty((self.num_envs, self.num_players), dtype=torch.float64, device=self._dev())

@@ -1,0 +1,49 @@
+"""Config 5 of BASELINE.json: 65 536 parallel 4-player games stepped by the action-mask policy model
+(rlskyjo/models/action_mask_model.py:13-77 restated without Ray, RLlib's default 256-256 tanh net, random weights)
+end-to-end on one GPU.  Per lockstep iteration: records -> zero-copy views -> policy net (torch / hipBLASLt GEMMs)
+-> masking + categorical draw -> skyjo_vec_step.  Two forms of the draw: plain torch (softmax + multinomial) and
+the fused HIP pass (skyjo_vec_sample_actions).   python tools/bench_cfg5.py [B] [iters]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from skyjo_rl_amd import SkyjoVecEnv
+from skyjo_rl_amd.action_mask_model import ActionMaskModel, sample_actions, sample_actions_fused
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 600
+torch.manual_seed(0)
+out = {"config": "65536 x 4 players, action-mask model in the loop" if B == 65536 else f"{B} x 4 players", "iters": ITERS}
+for dtype in (torch.float32, torch.bfloat16):
+    for form in ("torch", "fused"):
+        env = SkyjoVecEnv(B, num_players=4)
+        env.seed(None, 3)
+        model = ActionMaskModel(obs_dim=env.obs_dim).cuda()
+        rec = env.reset()
+        gen = torch.Generator(device="cuda").manual_seed(1)
+
+        def one(t, rec):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+                if form == "torch":
+                    v = env.split(rec)
+                    a = sample_actions(model, {"observations": v.observations, "action_mask": v.action_mask}, gen)
+                else:
+                    v = env.split(rec)
+                    logits = model.policy(v.observations.to(torch.float32)).float().contiguous()
+                    a = env.sample_actions(logits, rec, seed=9, ticket=t)
+            return env.step(a, out=rec)
+
+        for t in range(50):
+            rec = one(t, rec)
+        torch.cuda.synchronize()
+        c0 = env.counters()
+        t0 = time.perf_counter()
+        for t in range(ITERS):
+            rec = one(50 + t, rec)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        c1 = env.counters()
+        key = f"{form}_{'bf16' if dtype == torch.bfloat16 else 'fp32'}"
+        out[key] = {"env_steps_per_s": (c1["steps"] - c0["steps"]) / dt, "us_per_iteration": 1e6 * dt / ITERS,
+                    "illegal": c1["illegal"]}
+        env.close()
+print(json.dumps(out))
