@@ -802,7 +802,8 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
 // order (direct, skyjo.py:279-302).
 // ------------------------------------------------------------------------------------------
 template <bool INDIRECT>
-__device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, const HdrRegs &h, const ObsRegs &ob, uint8_t *out) {
+__device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, const HdrRegs &h, const ObsRegs &ob, uint8_t *out,
+                                            uint4 *held = nullptr) {
   const int phase = h.w0 & 0xff;
   const uint32_t q0 = ob.q0, q1 = ob.q1, q2 = ob.q2;
   uint32_t m[8];
@@ -820,16 +821,13 @@ __device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, cons
     uint4 a, b;
     a.x = LW(4), a.y = LW(5), a.z = LW(6), a.w = LW(7);
     b.x = s8 | (q0 << 24), b.y = (q0 >> 8) | (q1 << 24), b.z = (q1 >> 8) | (q2 << 24), b.w = q2 >> 8;
-#ifdef SK_EXP_COALESCED  // experiment only: right bytes, wrong places (lane-contiguous 1 KiB stores)
-    o = (uint4 *)(out - (size_t)(threadIdx.x) * 64) + threadIdx.x;
-    o[0] = a, o[64] = b;
-    o[128] = make_uint4(m[0], m[1], m[2], m[3]);
-    o[192] = make_uint4(m[4], m[5], m[6], m[7]);
-#else
-    o[0] = a, o[1] = b;
-    o[2] = make_uint4(m[0], m[1], m[2], m[3]);
-    o[3] = make_uint4(m[4], m[5], m[6], m[7]);
-#endif
+    if (held) {  // the caller stores the record itself
+      held[0] = a, held[1] = b, held[2] = make_uint4(m[0], m[1], m[2], m[3]), held[3] = make_uint4(m[4], m[5], m[6], m[7]);
+    } else {
+      o[0] = a, o[1] = b;
+      o[2] = make_uint4(m[0], m[1], m[2], m[3]);
+      o[3] = make_uint4(m[4], m[5], m[6], m[7]);
+    }
   } else {
     uint32_t *o = (uint32_t *)out;
     const int nv = 3 * P.L.N, v0 = P.L.off_vis >> 2;
@@ -946,6 +944,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
   uint8_t *fp = lp + P.L.chunks * 1024;  // 16-word per-lane scratch behind the tile (RNG FIFO)
   uint8_t *ap = (uint8_t *)lds_raw + P.L.chunks * 1024 + 4096 + lane * 8;  // 2N float64 accumulators per lane
+  uint8_t *stg = (uint8_t *)lds_raw + P.L.chunks * 1024 + 4096 + 2 * P.L.N * 512;  // 4 KiB: one iteration's records
   for (int k = 0; k < 2 * P.L.N; k++) ACC(k) = 0.0;
   STAMP_DECL;
   tile_load(P, P.state, tile, lane, lp);
@@ -1004,13 +1003,39 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
         STAMP(1);
       }
       obs_load(P, lp, (h.w0 >> 8) & 0xff, ob);  // one read of the row serves this record and the next iteration's turn
-      if (rec_out) emit_record<INDIRECT>(P, lp, h, ob, rec_out + ((size_t)it * P.B + g) * (size_t)P.L.rec_bytes);
-      if (act_out) act_out[(size_t)it * P.B + g] = a;
+      if (rec_out) {
+        if (INDIRECT) {  // staged in LDS, written by the whole wavefront below
+          uint4 rr[4];
+          emit_record<INDIRECT>(P, lp, h, ob, nullptr, rr);
+#pragma unroll
+          for (int p = 0; p < 4; p++) *(uint4 *)(stg + lane * 64 + ((p + (lane >> 1)) & 3) * 16) = rr[p];
+        } else {
+          emit_record<INDIRECT>(P, lp, h, ob, rec_out + ((size_t)it * P.B + g) * (size_t)P.L.rec_bytes);
+        }
+      }
+      if (act_out) __builtin_nontemporal_store(a, &act_out[(size_t)it * P.B + g]);
 #ifdef SK_STAMPS_FINE
       STAMP(7);
 #else
       STAMP(6);
 #endif
+    }
+    if (INDIRECT && rec_out) {
+      // The 64 records of the tile are one contiguous 4 KiB block of the output.  They pass through LDS so that each
+      // store instruction writes 1 KiB of it contiguously - full lines, one request per 64 bytes, instead of 64 pieces
+      // of 16 bytes at a 64-byte stride - and they are written non-temporally: the records are a stream nobody on
+      // this chip reads back, and kept out of the memory-side cache they leave the dealing kernel's generator state
+      // in it (k_step -7 %, k_deal -12 % together).  Staging slot of (record r, piece p): r * 64 + ((p + (r >> 1)) & 3)
+      // * 16 - both the lane-per-record writes above and the lane-per-16-bytes reads here are bank-conflict free.
+      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+      uint8_t *blk = rec_out + ((size_t)it * P.B + (size_t)tile * SK_TILE) * 64;
+      const int live = P.B - tile * SK_TILE;  // records of this tile that exist (the last tile may be partial)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int r = 16 * j + (lane >> 2), p = lane & 3;
+        const uint4 v = *(const uint4 *)(stg + r * 64 + ((p + (r >> 1)) & 3) * 16);
+        if (r < live) __builtin_nontemporal_store((u32x4_t){v.x, v.y, v.z, v.w}, (u32x4_t *)(blk + j * 1024 + lane * 16));
+      }
     }
   }
   HDR_FLUSH(h);
