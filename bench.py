@@ -26,7 +26,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
-CHUNK = int(os.environ.get("SKYJO_BENCH_CHUNK", "32"))  # lockstep iterations per kernel launch (<= kMaxRolloutChunk in skyjo_capi.hip)
+CHUNK = int(os.environ.get("SKYJO_BENCH_CHUNK", "80"))  # lockstep iterations per kernel launch (<= kMaxRolloutChunk in skyjo_capi.hip;
+                                                         # 80 = the engine's dealing interval for 3 and more players)
 
 
 def algorithmic_bytes_per_launch(B, N, D, iters, actions=True):
@@ -87,6 +88,9 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     B, N = args.num_envs, args.num_players
+    global CHUNK
+    if N < 3:
+        CHUNK = min(CHUNK, 64)  # the engine deals every 64 iterations below three players (shorter episodes)
     eng = SkyjoVecEnv(B, num_players=N, score_penalty=2.0, observe_other_player_indirect=True, mean_reward=1.0,
                       reward_refunded=0.001, device=local_rank,
                       rng_mode=RNG_MT19937 if args.rng == "mt19937" else RNG_PHILOX, auto_reset=True,
