@@ -43,8 +43,8 @@ ks = [k for k in pmc["fetch"] if k.startswith("k_step")][0]
 fk, wk = pmc["fetch"][ks]["FETCH_SIZE"], pmc["write"][ks]["WRITE_SIZE"]
 kd = [k for k in pmc["fetch"] if k.startswith("k_deal")][0]
 traffic = {
-    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/refresh_profiles.sh), bench.py --steps 64 "
-              "--warmup 16, 65536 x 3-player games, per k_step dispatch (32 lockstep iterations)",
+    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/refresh_profiles.sh), bench.py --steps 160 "
+              "--warmup 80, 65536 x 3-player games, per k_step dispatch (80 lockstep iterations)",
     "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
     "note": "gfx950: FETCH_SIZE counts half of a wide coalesced 16 B/lane stream (MI355X_MICROARCH.md, HBM) -> doubled; "
             "WRITE_SIZE is exact for 16 B/lane stores",

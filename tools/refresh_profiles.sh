@@ -11,10 +11,10 @@ rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" --steps 320 --warmup 32 --no-cpu-baseline > "$out/trace_bench.json" 2> "$out/trace.err"; echo "trace rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" --steps 800 --warmup 80 --no-cpu-baseline > "$out/trace_bench.json" 2> "$out/trace.err"; echo "trace rc=$?"
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "sq2 SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS"; do
   set -- $pass; tag=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/pmc_$tag" -- python3 "$root/bench.py" --steps 64 --warmup 16 --no-cpu-baseline > "$out/pmc_$tag.json" 2> "$out/pmc_$tag.err"; echo "pmc $tag rc=$?"
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/pmc_$tag" -- python3 "$root/bench.py" --steps 160 --warmup 80 --no-cpu-baseline > "$out/pmc_$tag.json" 2> "$out/pmc_$tag.err"; echo "pmc $tag rc=$?"
 done
 cd "$root"
 # keep the merge-back small: only the csv summaries
