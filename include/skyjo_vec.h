@@ -187,7 +187,7 @@ int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
 
 /* Tunables.  SKYJO_OPT_DEAL_INTERVAL: lockstep iterations (steps or rollout iterations) between two runs of the
  * dealing kernel (1..1024, default 80 for three and more players, 64 below; environment override SKYJO_DEAL_INTERVAL;
- * keep it below the mean episode length of the policy in use).  Every game owns a bank of four
+ * keep it below the mean episode length of the policy in use).  Every game owns a bank of three
  * pre-dealt episodes and a dealing run adds at most one per game; a finished game whose bank is empty deals in
  * place (slow path, same result, counted in skyjo_vec_counters.waits). */
 #define SKYJO_OPT_DEAL_INTERVAL 1
