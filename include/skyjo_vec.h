@@ -213,6 +213,20 @@ int skyjo_vec_sample_actions(skyjo_vec *h, const void *records, const float *log
                              uint64_t ticket, int32_t no_masking, int32_t *actions_out, float *logp_out,
                              float *uniform_out, void *stream);
 
+/* The policy net of config 5 on the matrix cores: RLlib's default fully connected net as the reference's
+ * TorchActionMaskModel builds it (rlskyjo/models/action_mask_model.py:41-52: obs -> 256 tanh -> 256 tanh -> outputs),
+ * evaluated for n records in one kernel that reads the int8 observation out of each record (indirect observation,
+ * obs_dim <= 31).  Weights are given once in torch.nn.Linear layout (row-major [out][in], float32, HOST pointers) and
+ * kept on the device as bf16 MFMA fragments; accumulation is float32.  out: float32 [n][out_dim] (device), out_dim <= 32
+ * (26 logits for the policy branch, 1 for the value branch).  Agreement with the float32 torch module is that of bf16
+ * weights and activations: see tests/test_gpu_policy_net.py for the stated tolerances. */
+typedef struct skyjo_vec_mlp skyjo_vec_mlp; /* opaque */
+int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, const float *w1, const float *b1,
+                         const float *w2, const float *b2, const float *w3, const float *b3, skyjo_vec_mlp **out);
+int skyjo_vec_mlp_destroy(skyjo_vec_mlp *m);
+int skyjo_vec_mlp_forward(const skyjo_vec_mlp *m, const void *records, int32_t record_bytes, int64_t n, float *out,
+                          void *stream);
+
 /* host-pointer conveniences for small batches (single-game AEC view): synchronous */
 int skyjo_vec_step_host(skyjo_vec *h, const int32_t *actions_host, void *records_out_host);
 int skyjo_vec_observe_host(skyjo_vec *h, const int32_t *players_host, void *records_out_host);

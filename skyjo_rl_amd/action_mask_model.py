@@ -61,3 +61,49 @@ def sample_actions_fused(model, env, records, seed=0, ticket=0, logp=None):
     model._last_obs = x
     logits = model.policy(x)
     return env.sample_actions(logits, records, seed=seed, ticket=ticket, no_masking=model.no_masking, logp=logp)
+
+
+class FusedNet:
+    """One branch of the model (``model.policy`` or ``model.value``: Linear-Tanh-Linear-Tanh-Linear with 256 hidden
+    units) packed for the MI355X matrix cores (``skyjo_vec_mlp_*``, csrc/skyjo_policy.h): bf16 weights as MFMA
+    fragments, float32 accumulation, observations read straight from the engine's records."""
+
+    def __init__(self, seq, device=0):
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _lib
+        lins = [m for m in seq if isinstance(m, nn.Linear)]
+        assert len(lins) == 3 and lins[0].out_features == 256 and lins[1].in_features == 256 and lins[1].out_features == 256
+        self.obs_dim, self.out_dim = lins[0].in_features, lins[2].out_features
+        arrs = []
+        for lin in lins:
+            arrs += [np.ascontiguousarray(lin.weight.detach().float().cpu().numpy()),
+                     np.ascontiguousarray(lin.bias.detach().float().cpu().numpy())]
+        self._L = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._L.skyjo_vec_mlp_create(int(device), self.obs_dim, self.out_dim,
+                                                *[a.ctypes.data_as(C.c_void_p) for a in arrs], C.byref(h)))
+        self._h, self._C, self._check = h, C, _lib.check
+
+    def __call__(self, records, out=None):
+        n = records.numel() // records.shape[-1]
+        if out is None:
+            out = torch.empty((n, self.out_dim), dtype=torch.float32, device=records.device)
+        C = self._C
+        self._check(self._L.skyjo_vec_mlp_forward(self._h, C.c_void_p(records.data_ptr()), int(records.shape[-1]), n,
+                                                  C.c_void_p(out.data_ptr()),
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
+
+    def close(self):
+        if self._h:
+            self._L.skyjo_vec_mlp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -7,6 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "skyjo_capi.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "skyjo_device.h"), os.path.join(HERE, "csrc", "skyjo_layout.h"),
+        os.path.join(HERE, "csrc", "skyjo_policy.h"),
         os.path.join(ROOT, "include", "skyjo_vec.h")]
 OUT = os.path.join(HERE, "libskyjo_vec.so")
 

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "skyjo_device.h"
+#include "skyjo_policy.h"
 
 namespace {
 
@@ -37,6 +38,12 @@ constexpr int kMaxRolloutChunk = 128;  // lockstep iterations per k_step launch 
 constexpr int deal_interval_default(int num_players) { return num_players >= 3 ? 80 : 64; }
 
 }  // namespace
+
+struct skyjo_vec_mlp {
+  SkMlpDev net{};
+  void *blob = nullptr;
+  int device_id = 0, obs_dim = 0;
+};
 
 struct skyjo_vec {
   skyjo_vec_config cfg{};
@@ -385,6 +392,87 @@ int skyjo_vec_sample_actions(skyjo_vec *h, const void *records, const float *log
   hipLaunchKernelGGL(k_sample, dim3((unsigned)blocks), dim3(SK_SAMPLE_BLOCK), 0, (hipStream_t)stream, h->P.L,
                      (const uint8_t *)records, logits, (long long)n, seed, ticket, h->P.game_id0, (int)no_masking,
                      actions_out, logp_out, uniform_out);
+  HIPCHK(hipGetLastError());
+  return SKYJO_OK;
+}
+
+int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, const float *w1, const float *b1,
+                         const float *w2, const float *b2, const float *w3, const float *b3, skyjo_vec_mlp **out) {
+  if (!out || !w1 || !b1 || !w2 || !b2 || !w3 || !b3) return fail(SKYJO_E_INVALID, "null argument");
+  if (obs_dim < 1 || obs_dim > SKP_IN - 1 || out_dim < 1 || out_dim > SKP_OUT)
+    return fail(SKYJO_E_INVALID, "skyjo_vec_mlp: obs_dim must be 1..31 and out_dim 1..32");
+  HIPCHK(hipSetDevice(device_id));
+  auto bf16 = [](float f) {  // round to nearest even
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  };
+  auto acc_k = [](int ks, int hh, int j) { return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * hh + (j & 3); };
+  const int H = SKP_HIDDEN;
+  std::vector<uint16_t> f1((size_t)8 * 2 * 64 * 8), f2((size_t)8 * 16 * 64 * 8), f3((size_t)16 * 64 * 8);
+  std::vector<float> c2((size_t)8 * 64 * 16), c3((size_t)64 * 16);
+  for (int u = 0; u < 8; u++)
+    for (int l = 0; l < 64; l++) {
+      const int m = 32 * u + (l & 31), hh = l >> 5;
+      for (int s = 0; s < 2; s++)
+        for (int j = 0; j < 8; j++) {
+          const int k = 16 * s + 8 * hh + j;  // natural order: the kernel builds this operand from the record itself
+          const float v = k < obs_dim ? w1[(size_t)m * obs_dim + k] : (k == SKP_IN - 1 ? b1[m] : 0.f);
+          f1[(((size_t)u * 2 + s) * 64 + l) * 8 + j] = bf16(v);
+        }
+      for (int ks = 0; ks < 16; ks++)
+        for (int j = 0; j < 8; j++) f2[(((size_t)u * 16 + ks) * 64 + l) * 8 + j] = bf16(w2[(size_t)m * H + acc_k(ks, hh, j)]);
+      for (int r = 0; r < 16; r++) c2[((size_t)u * 64 + l) * 16 + r] = b2[32 * u + (r & 3) + 8 * (r >> 2) + 4 * hh];
+    }
+  for (int l = 0; l < 64; l++) {
+    const int m = l & 31, hh = l >> 5;
+    for (int ks = 0; ks < 16; ks++)
+      for (int j = 0; j < 8; j++) f3[((size_t)ks * 64 + l) * 8 + j] = m < out_dim ? bf16(w3[(size_t)m * H + acc_k(ks, hh, j)]) : 0;
+    for (int r = 0; r < 16; r++) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      c3[(size_t)l * 16 + r] = row < out_dim ? b3[row] : 0.f;
+    }
+  }
+  skyjo_vec_mlp *m = new skyjo_vec_mlp();
+  m->device_id = device_id, m->obs_dim = obs_dim;
+  const size_t n1 = f1.size() * 2, n2 = f2.size() * 2, n3 = f3.size() * 2, nb2 = c2.size() * 4, nb3 = c3.size() * 4;
+  if (hipMalloc(&m->blob, n1 + n2 + n3 + nb2 + nb3) != hipSuccess) {
+    delete m;
+    return fail(SKYJO_E_DEVICE, "hipMalloc failed for the packed weights");
+  }
+  uint8_t *p = (uint8_t *)m->blob;
+  hipError_t e = hipMemcpy(p, f1.data(), n1, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p + n1, f2.data(), n2, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p + n1 + n2, f3.data(), n3, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p + n1 + n2 + n3, c2.data(), nb2, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p + n1 + n2 + n3 + nb2, c3.data(), nb3, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(m->blob);
+    delete m;
+    return fail(SKYJO_E_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
+  }
+  m->net.w1 = (const uint4 *)p, m->net.w2 = (const uint4 *)(p + n1), m->net.w3 = (const uint4 *)(p + n1 + n2);
+  m->net.b2 = (const float *)(p + n1 + n2 + n3), m->net.b3 = (const float *)(p + n1 + n2 + n3 + nb2);
+  m->net.out_dim = out_dim;
+  *out = m;
+  return SKYJO_OK;
+}
+
+int skyjo_vec_mlp_destroy(skyjo_vec_mlp *m) {
+  if (!m) return SKYJO_OK;
+  (void)hipFree(m->blob);
+  delete m;
+  return SKYJO_OK;
+}
+
+int skyjo_vec_mlp_forward(const skyjo_vec_mlp *m, const void *records, int32_t record_bytes, int64_t n, float *out,
+                          void *stream) {
+  if (!m || !records || !out || n < 0 || record_bytes < 32 || (record_bytes & 15))
+    return fail(SKYJO_E_INVALID, "skyjo_vec_mlp_forward: bad argument");
+  if (n == 0) return SKYJO_OK;
+  hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT - 1) / (32 * SKP_GT))), dim3(64), 0, (hipStream_t)stream, m->net,
+                     (const uint8_t *)records, (int)record_bytes, m->obs_dim, (long long)n, out);
   HIPCHK(hipGetLastError());
   return SKYJO_OK;
 }

@@ -1,0 +1,143 @@
+// skyjo_policy.h - config 5 caller: the fully connected net of the action-mask policy model
+// (rlskyjo/models/action_mask_model.py:41-52 builds RLlib's TorchFC: obs -> 256 tanh -> 256 tanh -> outputs) as ONE
+// gfx950 kernel on the matrix cores, reading the observation bytes straight out of the engine's records.
+//
+// Orientation: everything is computed transposed, H_next^T = W^T * H^T, with the 32 games of a wavefront on the lanes
+// (MFMA column index) and the hidden units on the accumulator registers (row index).  A 32x32 accumulator tile of
+// v_mfma_f32_32x32x16_bf16 can then be fed to the next layer as the B operand without any lane movement or LDS: its
+// registers 8s .. 8s+7, packed to bf16, ARE the fragment of k-step s - in a permuted k order (element j of lane half h
+// is row 16s + 8(j>>2) + 4h + (j&3) of the tile), which the weights follow: they are packed on the host, once, into
+// exactly the per-lane fragments the kernel loads (one 16-byte load per lane and MFMA).
+// Lane maps (gfx950): A[row l&31][k = 8(l>>5)+j], B[k = 8(l>>5)+j][col l&31], C[row (r&3)+8(r>>2)+4(l>>5)][col l&31].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SKP_HIDDEN 256
+#define SKP_IN 32    // 31 observation features + a constant 1 that carries the first layer's bias
+#define SKP_OUT 32   // up to 32 outputs (26 logits, or 1 value)
+
+typedef __bf16 skp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float skp_f32x16 __attribute__((ext_vector_type(16)));
+
+struct SkMlpDev {
+  const uint4 *w1;   // [8 m-tiles][2 k-steps][64 lanes] fragments, natural k order (k = feature)
+  const uint4 *w2;   // [8][16][64] fragments, accumulator k order
+  const uint4 *w3;   // [1][16][64]
+  const float *b2;   // [8][64 lanes][16 regs] bias of layer 2 in accumulator layout
+  const float *b3;   // [1][64][16]
+  int out_dim;
+};
+
+__device__ __forceinline__ float skp_tanh(float x) {
+  const float t = __expf(2.0f * x);  // inf for large x -> 1, 0 for very negative x -> -1
+  return 1.0f - 2.0f / (t + 1.0f);
+}
+__device__ __forceinline__ skp_bf16x8 skp_pack8(const skp_f32x16 &a, int s, bool act) {
+  skp_bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; j++) r[j] = (__bf16)(act ? skp_tanh(a[8 * s + j]) : a[8 * s + j]);
+  return r;
+}
+__device__ __forceinline__ skp_bf16x8 skp_frag(const uint4 *p) {
+  const uint4 q = *p;
+  skp_bf16x8 r;
+  __builtin_memcpy(&r, &q, 16);
+  return r;
+}
+
+// One wavefront = SKP_GT column tiles of 32 games: every weight fragment that is loaded feeds SKP_GT independent MFMAs
+// (half the weight traffic per game at 2, and two accumulators in flight instead of one dependent chain).
+// rec_bytes / obs_dim as in the engine's records (indirect observation: 31 int8 features).
+#define SKP_GT 1  // (2: 47.7 us vs 42.7 us per 65 536 records - the kernel is bound by its 512 tanh per game, not by weight traffic)
+__global__ __launch_bounds__(64) void k_mlp_forward(SkMlpDev net, const uint8_t *rec, int rec_bytes, int obs_dim, long long n,
+                                                     float *out) {
+  const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
+  long long g[SKP_GT];
+  skp_bf16x8 x[SKP_GT][2];
+#pragma unroll
+  for (int c = 0; c < SKP_GT; c++) {
+    g[c] = ((long long)blockIdx.x * SKP_GT + c) * 32 + col;
+    // ---- input fragments: features 16s + 8h .. 16s + 8h + 7 of this lane's game, int8 -> bf16 (exact) ----
+    uint32_t ob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (g[c] < n) {
+      const uint4 *r = (const uint4 *)(rec + g[c] * rec_bytes);
+      const uint4 a = r[0], b = r[1];
+      ob[0] = a.x, ob[1] = a.y, ob[2] = a.z, ob[3] = a.w, ob[4] = b.x, ob[5] = b.y, ob[6] = b.z, ob[7] = b.w;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int k0 = 16 * s + j, k1 = 16 * s + 8 + j;  // the feature index 16s + 8h + j for h = 0 / h = 1
+        const float v0 = k0 < obs_dim ? (float)(int8_t)(ob[k0 >> 2] >> ((k0 & 3) * 8)) : (k0 == SKP_IN - 1 ? 1.0f : 0.0f);
+        const float v1 = k1 < obs_dim ? (float)(int8_t)(ob[k1 >> 2] >> ((k1 & 3) * 8)) : (k1 == SKP_IN - 1 ? 1.0f : 0.0f);
+        x[c][s][j] = (__bf16)(h ? v1 : v0);
+      }
+  }
+  // ---- layer 1: 31 (+1) -> 256, tanh; the result tiles become the 16 k-step fragments of layer 2 ----
+  skp_bf16x8 h1[SKP_GT][16];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    skp_f32x16 acc[SKP_GT];
+#pragma unroll
+    for (int c = 0; c < SKP_GT; c++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[c][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const skp_bf16x8 w = skp_frag(net.w1 + (u * 2 + s) * 64 + lane);
+#pragma unroll
+      for (int c = 0; c < SKP_GT; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x[c][s], acc[c], 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < SKP_GT; c++) h1[c][2 * u] = skp_pack8(acc[c], 0, true), h1[c][2 * u + 1] = skp_pack8(acc[c], 1, true);
+  }
+  // ---- layer 2: 256 -> 256, tanh ----
+  skp_bf16x8 h2[SKP_GT][16];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    skp_f32x16 acc[SKP_GT];
+    const float4 *bp = (const float4 *)(net.b2 + ((size_t)u * 64 + lane) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float4 b = bp[q];
+#pragma unroll
+      for (int c = 0; c < SKP_GT; c++) acc[c][4 * q] = b.x, acc[c][4 * q + 1] = b.y, acc[c][4 * q + 2] = b.z, acc[c][4 * q + 3] = b.w;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 16; ks++) {
+      const skp_bf16x8 w = skp_frag(net.w2 + (u * 16 + ks) * 64 + lane);
+#pragma unroll
+      for (int c = 0; c < SKP_GT; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, h1[c][ks], acc[c], 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < SKP_GT; c++) h2[c][2 * u] = skp_pack8(acc[c], 0, true), h2[c][2 * u + 1] = skp_pack8(acc[c], 1, true);
+  }
+  // ---- layer 3: 256 -> outputs (no activation) ----
+  skp_f32x16 acc[SKP_GT];
+  {
+    const float4 *bp = (const float4 *)(net.b3 + (size_t)lane * 16);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float4 b = bp[q];
+#pragma unroll
+      for (int c = 0; c < SKP_GT; c++) acc[c][4 * q] = b.x, acc[c][4 * q + 1] = b.y, acc[c][4 * q + 2] = b.z, acc[c][4 * q + 3] = b.w;
+    }
+  }
+#pragma unroll
+  for (int ks = 0; ks < 16; ks++) {
+    const skp_bf16x8 w = skp_frag(net.w3 + ks * 64 + lane);
+#pragma unroll
+    for (int c = 0; c < SKP_GT; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, h2[c][ks], acc[c], 0, 0, 0);
+  }
+#pragma unroll
+  for (int c = 0; c < SKP_GT; c++)
+    if (g[c] < n) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < net.out_dim) out[g[c] * net.out_dim + row] = acc[c][r];
+      }
+    }
+}

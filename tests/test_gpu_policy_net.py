@@ -1,0 +1,84 @@
+"""the policy net of config 5 on the matrix cores (skyjo_vec_mlp_forward, csrc/skyjo_policy.h) against
+torch.  Floating point - the kernel keeps weights and inter-layer activations in bf16 and accumulates in float32:
+  * against a torch float32 emulation of exactly that arithmetic (bf16-rounded weights, activations rounded to bf16
+    after tanh): max |diff| of the outputs < 2e-2 and mean |diff| < 2e-3 (what is left is the fast tanh, the order of
+    the float32 sums and the bf16 roundings that flip because of them);
+  * against the plain float32 module: max |diff| < 8e-2, mean < 1e-2, and the action distributions agree
+    (mean KL(softmax fp32 || softmax kernel) < 1e-3)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _emulate(seq, x):
+    import torch
+    from torch import nn
+
+    h = x
+    lins = [m for m in seq if isinstance(m, nn.Linear)]
+    for i, lin in enumerate(lins):
+        w = lin.weight.detach().bfloat16().float()
+        b = lin.bias.detach().float() if i else lin.bias.detach().bfloat16().float()  # layer 1's bias rides in the GEMM
+        h = h @ w.t() + b
+        if i < 2:
+            h = torch.tanh(h).bfloat16().float()
+    return h
+
+
+@pytest.mark.parametrize("N,B,branch", [(4, 8192, "policy"), (3, 1000, "policy"), (2, 33, "value"), (4, 65536, "value")])
+def test_policy_net_matches_torch(N, B, branch):
+    import torch
+
+    from skyjo_rl_amd import SkyjoVecEnv
+    from skyjo_rl_amd.action_mask_model import ActionMaskModel, FusedNet
+
+    torch.manual_seed(1)
+    env = SkyjoVecEnv(B, num_players=N)
+    env.seed(None, 5)
+    model = ActionMaskModel(obs_dim=env.obs_dim).cuda()
+    with torch.no_grad():  # weights well away from zero so that every hidden unit matters
+        for p in model.parameters():
+            p.mul_(1.5)
+    seq = model.policy if branch == "policy" else model.value
+    net = FusedNet(seq)
+    rec = env.reset()
+    for t in range(5):
+        rec = env.step(env.sample_actions(torch.zeros((B, 26), device="cuda"), rec, seed=1, ticket=t))
+    x = env.split(rec).observations.to(torch.float32)
+    got = net(rec)
+    with torch.no_grad():
+        emu = _emulate(seq, x)
+        ref = seq(x)
+    assert got.shape == ref.shape
+    d = (got - emu).abs()
+    assert float(d.max()) < 2e-2 and float(d.mean()) < 2e-3, (float(d.max()), float(d.mean()))
+    d32 = (got - ref).abs()
+    assert float(d32.max()) < 8e-2 and float(d32.mean()) < 1e-2, (float(d32.max()), float(d32.mean()))
+    if branch == "policy":
+        kl = (torch.softmax(ref, -1) * (torch.log_softmax(ref, -1) - torch.log_softmax(got, -1))).sum(-1)
+        assert float(kl.mean()) < 1e-3
+    net.close()
+    env.close()
+
+
+def test_fused_policy_loop_plays_legal_games():
+    import torch
+
+    from skyjo_rl_amd import SkyjoVecEnv
+    from skyjo_rl_amd.action_mask_model import ActionMaskModel, FusedNet
+
+    torch.manual_seed(0)
+    B = 4096
+    env = SkyjoVecEnv(B, num_players=4)
+    env.seed(None, 3)
+    model = ActionMaskModel(obs_dim=env.obs_dim).cuda()
+    pol, val = FusedNet(model.policy), FusedNet(model.value)
+    rec = env.reset()
+    for t in range(300):
+        logits = pol(rec)
+        rec = env.step(env.sample_actions(logits, rec, seed=4, ticket=t))
+    assert val(rec).shape == (B, 1)
+    c = env.counters()
+    assert c["illegal"] == 0 and c["episodes"] > 0
+    env.close()

@@ -2,26 +2,33 @@
 (rlskyjo/models/action_mask_model.py:13-77 restated without Ray, RLlib's default 256-256 tanh net, random weights)
 end-to-end on one GPU.  Per lockstep iteration: records -> zero-copy views -> policy net (torch / hipBLASLt GEMMs)
 -> masking + categorical draw -> skyjo_vec_step.  Two forms of the draw: plain torch (softmax + multinomial) and
-the fused HIP pass (skyjo_vec_sample_actions).   python tools/bench_cfg5.py [B] [iters]"""
+the fused HIP pass (skyjo_vec_sample_actions); "mfma" additionally runs the policy net as the hand-written MFMA
+kernel (skyjo_vec_mlp_forward) instead of torch.   python tools/bench_cfg5.py [B] [iters]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from skyjo_rl_amd import SkyjoVecEnv
-from skyjo_rl_amd.action_mask_model import ActionMaskModel, sample_actions, sample_actions_fused
+from skyjo_rl_amd.action_mask_model import ActionMaskModel, FusedNet, sample_actions, sample_actions_fused
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 torch.manual_seed(0)
 out = {"config": "65536 x 4 players, action-mask model in the loop" if B == 65536 else f"{B} x 4 players", "iters": ITERS}
 for dtype in (torch.float32, torch.bfloat16):
-    for form in ("torch", "fused"):
+    for form in ("torch", "fused", "mfma"):
+        if form == "mfma" and dtype != torch.bfloat16:
+            continue
         env = SkyjoVecEnv(B, num_players=4)
         env.seed(None, 3)
         model = ActionMaskModel(obs_dim=env.obs_dim).cuda()
         rec = env.reset()
         gen = torch.Generator(device="cuda").manual_seed(1)
+        pol = FusedNet(model.policy) if form == "mfma" else None
+        logits_buf = torch.empty((B, 26), dtype=torch.float32, device="cuda")
 
         def one(t, rec):
+            if form == "mfma":  # policy net on the matrix cores (skyjo_vec_mlp_forward) + fused draw + env step: 3 launches
+                return env.step(env.sample_actions(pol(rec, out=logits_buf), rec, seed=9, ticket=t), out=rec)
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
                 if form == "torch":
                     v = env.split(rec)
