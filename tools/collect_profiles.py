@@ -1,9 +1,9 @@
 """Digest gpurun_out/final/ (written by tools/refresh_profiles.sh on the GPU box) into profiles/r1_*.  Run from the repo root."""
 import collections, csv, glob, json, os, shutil, sys
 src, dst = "gpurun_out/final", "profiles"
-def find(pat):
-    r = glob.glob(os.path.join(src, pat), recursive=True)
-    return r[0] if r else None
+def find(pat):  # newest match: gpurun merges every refresh into the same local directory
+    r = sorted(glob.glob(os.path.join(src, pat), recursive=True), key=os.path.getmtime)
+    return r[-1] if r else None
 def short(name):
     return name.split("(")[0].replace("void ", "").strip()
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
