@@ -186,8 +186,9 @@ int skyjo_vec_profile(skyjo_vec *h, int enable, double *step_ms, int64_t *step_l
 int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
 
 /* Tunables.  SKYJO_OPT_DEAL_INTERVAL: lockstep iterations (steps or rollout iterations) between two runs of the
- * dealing kernel (1..1024, default 80 for three and more players, 64 below; environment override SKYJO_DEAL_INTERVAL;
- * keep it below the mean episode length of the policy in use).  Every game owns a bank of three
+ * dealing kernel (1..1024; environment override SKYJO_DEAL_INTERVAL).  Unless it is set, the engine starts at 80 (three
+ * and more players) or 64 and adapts: every dealing run reports how many banks it found empty, any empty bank shortens
+ * the interval, a long calm stretch lengthens it again - so it settles below the episode length of the policy in use.  Every game owns a bank of three
  * pre-dealt episodes and a dealing run adds at most one per game; a finished game whose bank is empty deals in
  * place (slow path, same result, counted in skyjo_vec_counters.waits). */
 #define SKYJO_OPT_DEAL_INTERVAL 1
@@ -196,6 +197,7 @@ int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
  * environment override SKYJO_OVERLAP).  Results do not depend on this setting. */
 #define SKYJO_OPT_OVERLAP 2
 int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value);
+int skyjo_vec_get_option(const skyjo_vec *h, int option, int64_t *value_out);
 
 /* Caller piece of config 5: the masking and sampling step of the action-mask policy model,
  * rlskyjo/models/action_mask_model.py:58-74 -  masked = logits + clamp(log(action_mask), min=FLOAT_MIN)  - followed

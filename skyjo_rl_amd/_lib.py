@@ -79,6 +79,7 @@ SIGNATURES = {
                                     C.POINTER(I64)]),
     "skyjo_vec_debug_stamps": (C.c_int, [VP, VP]),
     "skyjo_vec_set_option": (C.c_int, [VP, C.c_int, I64]),
+    "skyjo_vec_get_option": (C.c_int, [VP, C.c_int, C.POINTER(I64)]),
     "skyjo_vec_step_host": (C.c_int, [VP, VP, VP]),
     "skyjo_vec_observe_host": (C.c_int, [VP, VP, VP]),
     "skyjo_vec_reset_host": (C.c_int, [VP, VP, VP]),

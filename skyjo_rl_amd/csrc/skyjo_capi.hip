@@ -53,6 +53,13 @@ struct skyjo_vec {
   bool seeded = false;
   int pending_iters = 0;  // lockstep iterations since the dealing kernel last ran
   int deal_every_iters = 64;  // set from deal_interval_default() in skyjo_vec_create
+  // The interval adapts itself unless it was set explicitly: every dealing run reports how many banks it found empty
+  // (host-mapped word, no synchronisation); any empty bank shortens the interval, a long calm stretch lengthens it
+  // back towards the default.  Results never depend on the cadence (tests/test_gpu_parity.py), only the speed does.
+  bool auto_interval = true;
+  int interval_default = 64, calm_runs = 0;
+  uint32_t health_seen = 0;
+  uint32_t *health_host = nullptr;
   // dealing pipeline: k_scan / k_publish on the caller's stream, k_deal on deal_stream when overlap is on
   bool overlap = true;
   hipStream_t deal_stream = nullptr;
@@ -111,6 +118,21 @@ int publish_deals(skyjo_vec *h, hipStream_t s) {
 int start_deals(skyjo_vec *h, hipStream_t s) {
   int rc;
   if ((rc = publish_deals(h, s))) return rc;
+  if (h->auto_interval) {
+    const volatile uint32_t *hh = h->health_host;
+    const uint32_t tag = hh[1], empty = hh[0];
+    if (tag != h->health_seen) {  // the report of a run that has finished since the last look (one or two runs old)
+      h->health_seen = tag;
+      if (empty) {
+        const int cut = h->deal_every_iters / 8 > 4 ? h->deal_every_iters / 8 : 4;
+        h->deal_every_iters = h->deal_every_iters - cut > 8 ? h->deal_every_iters - cut : 8;
+        h->calm_runs = 0;
+      } else if (++h->calm_runs >= 32 && h->deal_every_iters < h->interval_default) {
+        h->deal_every_iters += 2;
+        h->calm_runs = 16;
+      }
+    }
+  }
   h->list_sel ^= 1;
   h->deal_tag = (h->deal_tag + 1) & 0x7fffffffu;
   if (h->deal_tag == 0) h->deal_tag = 1;
@@ -229,7 +251,7 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
       (rc = dalloc(h, &P.spare_ready, SK_BANK * h->G)) || (rc = dalloc(h, &P.bank_head, h->G)) ||
       (rc = dalloc(h, &P.busy, h->G)) || (rc = dalloc(h, &P.cancel, h->G)) || (rc = dalloc(h, &P.done_flag, h->G)) ||
       (rc = dalloc(h, &P.deal_list, 2 * h->G)) || (rc = dalloc(h, &P.deal_ep, 2 * h->G)) ||
-      (rc = dalloc(h, &P.deal_count, 2)) ||
+      (rc = dalloc(h, &P.deal_count, 2)) || (rc = dalloc(h, &P.bank_empty, 1)) ||
       (rc = dalloc(h, &P.mt_idx, (1 + SK_BANK) * h->G)) || (rc = dalloc(h, &P.seeds, h->G)) ||
       (rc = dalloc(h, &P.deals_consumed, h->G)) || (rc = dalloc(h, &P.rewards, h->G * N)) ||
       (rc = dalloc(h, &P.scores, h->G * N)) || (rc = dalloc(h, &P.done, h->G)) ||
@@ -248,12 +270,22 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     skyjo_vec_destroy(h);
     return fail(SKYJO_E_DEVICE, "cannot create the dealing stream / events");
   }
-  h->deal_every_iters = deal_interval_default(cfg->num_players);
+  {
+    void *dp = nullptr;
+    if (hipHostMalloc((void **)&h->health_host, 2 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(&dp, h->health_host, 0) != hipSuccess) {
+      skyjo_vec_destroy(h);
+      return fail(SKYJO_E_DEVICE, "cannot map the bank-health word");
+    }
+    h->health_host[0] = h->health_host[1] = 0;
+    P.health_host = (volatile uint32_t *)dp;
+  }
+  h->deal_every_iters = h->interval_default = deal_interval_default(cfg->num_players);
   h->overlap = false;  // SKYJO_OPT_OVERLAP / SKYJO_OVERLAP=1 switch the second stream on
   if (const char *e = getenv("SKYJO_OVERLAP")) h->overlap = atoi(e) != 0;
   if (const char *e = getenv("SKYJO_DEAL_INTERVAL")) {
     const int v = atoi(e);
-    if (v >= 1 && v <= 1024) h->deal_every_iters = v;
+    if (v >= 1 && v <= 1024) h->deal_every_iters = v, h->auto_interval = false;
   }
   *out = h;
   return SKYJO_OK;
@@ -266,6 +298,7 @@ int skyjo_vec_destroy(skyjo_vec *h) {
   if (h->ev_scan) (void)hipEventDestroy(h->ev_scan);
   if (h->ev_dealt) (void)hipEventDestroy(h->ev_dealt);
   for (void *p : h->allocs) (void)hipFree(p);
+  if (h->health_host) (void)hipHostFree(h->health_host);
   delete h;
   return SKYJO_OK;
 }
@@ -342,7 +375,9 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
   hipStream_t s = (hipStream_t)stream;
   uint8_t *rec = (uint8_t *)records_out;
   for (int done = 0; done < iters;) {
-    const int n = iters - done < kMaxRolloutChunk ? iters - done : kMaxRolloutChunk;
+    int n = iters - done < kMaxRolloutChunk ? iters - done : kMaxRolloutChunk;
+    const int until_deal = h->deal_every_iters - h->pending_iters;  // (a launch never runs past the next dealing run)
+    if (until_deal >= 1 && n > until_deal) n = until_deal;
     int rc = launch_step(h, s, true, nullptr, rec, actions_out, n, policy_seed);
     if (rc) return rc;
     done += n;
@@ -657,12 +692,21 @@ int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host) {
   return SKYJO_OK;
 }
 
+int skyjo_vec_get_option(const skyjo_vec *h, int option, int64_t *value_out) {
+  if (!h || !value_out) return fail(SKYJO_E_INVALID, "null argument");
+  switch (option) {
+    case SKYJO_OPT_DEAL_INTERVAL: *value_out = h->deal_every_iters; return SKYJO_OK;
+    case SKYJO_OPT_OVERLAP: *value_out = h->overlap ? 1 : 0; return SKYJO_OK;
+    default: return fail(SKYJO_E_INVALID, "unknown option");
+  }
+}
+
 int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
   switch (option) {
     case SKYJO_OPT_DEAL_INTERVAL:
       if (value < 1 || value > 1024) return fail(SKYJO_E_INVALID, "deal interval must be in 1..1024");
-      h->deal_every_iters = (int)value;
+      h->deal_every_iters = (int)value, h->auto_interval = false;
       return SKYJO_OK;
     case SKYJO_OPT_OVERLAP: {
       int rc = publish_deals(h, nullptr);  // drain the pipeline before changing its shape

@@ -46,6 +46,8 @@ struct SkParams {
   int32_t *deal_list;       // [2][tiles*64] games of the current / previous dealing launch (k_scan)
   uint32_t *deal_ep;        // [2][tiles*64] episode index of each listed deal
   uint32_t *deal_count;     // [2]
+  uint32_t *bank_empty;     // [1] games whose bank held no episode when the last k_scan looked (early warning of a drain)
+  volatile uint32_t *health_host;  // [2] host-mapped: {that count, dealing-run tag} - written once per run, read by the host
   uint32_t *mt;             // [tiles*64][624] numpy-legacy MT19937 state, advanced in place (mt_untwist steps it back)
   int32_t *mt_idx;          // [1+SK_BANK][tiles*64]: [0] stream position (idx | ahead << 16), [1 + slot] position before its deal
   uint64_t *seeds;          // [tiles*64] value given to set_seed
@@ -1667,7 +1669,11 @@ __global__ __launch_bounds__(SK_SCAN_BLOCK) void k_scan(SkParams P, int list_sel
       slot = (head + r) % SK_BANK;  // slots fill in stream order
     }
     const unsigned long long b = __ballot(need);
-    if (lane == 0) wave_need[wave] = (uint32_t)__popcll(b);
+    const unsigned long long be = __ballot(need && r == 0);  // nothing in the bank: one more game end before the next run deals in place
+    if (lane == 0) {
+      wave_need[wave] = (uint32_t)__popcll(b);
+      if (be) atomicAdd(P.bank_empty, (uint32_t)__popcll(be));  // (rare)
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
       uint32_t total = 0;
@@ -1697,7 +1703,11 @@ __global__ __launch_bounds__(256) void k_publish(SkParams P, int list_sel) {
   const size_t G = (size_t)P.tiles * SK_TILE;
   const int32_t *list = P.deal_list + (size_t)list_sel * G;
   const int count = (int)P.deal_count[list_sel];
-  if (blockIdx.x == 0 && threadIdx.x == 0) P.deal_count[list_sel ^ 1] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    P.deal_count[list_sel ^ 1] = 0;
+    P.health_host[0] = *P.bank_empty, P.health_host[1] = P.deal_tag;
+    *P.bank_empty = 0;
+  }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     const int g = list[i];
     const int slot = P.busy[g] - 1;
@@ -1714,7 +1724,11 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
   const size_t G = (size_t)P.tiles * SK_TILE;
   const int count = (int)P.deal_count[list_sel];
   const int i = blockIdx.x * SK_TILE + lane;
-  if (publish_inline && blockIdx.x == 0 && lane == 0) P.deal_count[list_sel ^ 1] = 0;  // for the next run's k_scan
+  if (publish_inline && blockIdx.x == 0 && lane == 0) {
+    P.deal_count[list_sel ^ 1] = 0;  // for the next run's k_scan
+    P.health_host[0] = *P.bank_empty, P.health_host[1] = P.deal_tag;  // (host-mapped memory: the host adapts the dealing interval)
+    *P.bank_empty = 0;
+  }
   if (blockIdx.x * SK_TILE >= count) return;
   const int tile = blockIdx.x;  // stamp slot
   (void)tile;

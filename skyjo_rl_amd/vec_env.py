@@ -243,6 +243,12 @@ class SkyjoVecEnv:
     def set_deal_interval(self, n):
         _lib.check(self._L.skyjo_vec_set_option(self._h, 1, int(n)))
 
+    def deal_interval(self):
+        """Lockstep iterations between two dealing runs right now (it adapts itself unless set explicitly)."""
+        v = C.c_int64()
+        _lib.check(self._L.skyjo_vec_get_option(self._h, 1, C.byref(v)))
+        return int(v.value)
+
     def set_overlap(self, on):
         """Run the dealing kernel on its own stream beside the step kernels (results do not depend on it)."""
         _lib.check(self._L.skyjo_vec_set_option(self._h, 2, int(bool(on))))

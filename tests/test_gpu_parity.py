@@ -290,3 +290,32 @@ def test_headline_size_properties():
         collapsed = int((s["masked"] == 0).sum()) // 3
         assert s["n_draw"] + s["n_disc"] + (s["hand"] != 15) == 150 - 12 * N + 3 * collapsed
     eng.close()
+
+
+def test_dealing_interval_adapts_to_short_episodes():
+    """One-player games end after ~25 steps: at the default interval of 64 the banks run dry and finished games deal in
+    place (exact, slow).  The engine sees the empty banks in its dealing runs and shortens the interval by itself; the
+    trajectories do not depend on it (same oracle comparison as everywhere)."""
+    import torch
+
+    B = 512
+    cfg = dict(num_players=1, score_penalty=2.0, observe_other_player_indirect=True, mean_reward=1.0,
+               reward_refunded=0.001, rng_mode=0, auto_reset=True)
+    eng = _engine(B, **cfg)
+    ora = _oracle_vec(num_envs=B, **cfg)
+    eng.seed(None, 5)
+    ora.seed(None, 5)
+    assert eng.deal_interval() == 64
+    early = late = 0
+    for r in range(60):
+        act = torch.empty((32, B), dtype=torch.int32, device="cuda")
+        w0 = eng.counters()["waits"]
+        eng.rollout(32, policy_seed=3, actions=act)
+        oact = ora.rollout(32, 3, record_actions=True)
+        np.testing.assert_array_equal(act.cpu().numpy(), oact, err_msg=f"actions round {r}")
+        w = eng.counters()["waits"] - w0
+        early += w if r < 10 else 0
+        late += w if r >= 50 else 0
+    assert eng.deal_interval() < 40
+    assert early > 0 and late < early / 4
+    eng.close()
