@@ -1,0 +1,45 @@
+"""the on-device rollout collector (skyjo_rl_amd/rollout.py) - columns are consistent with each other and
+with the engine: recorded actions are legal under the recorded masks, recorded log-probabilities equal the masked
+log-softmax of the (recomputed) logits at the recorded action within 1e-5, episode ends carry the rewards of
+skyjo_env.py:293-312 (per game they sum to N * mean_reward + refund bonus)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rollout_buffer_columns_are_consistent():
+    import torch
+
+    from skyjo_rl_amd import SkyjoVecEnv
+    from skyjo_rl_amd.action_mask_model import ActionMaskModel, FusedNet
+    from skyjo_rl_amd.rollout import RolloutBuffer, collect
+
+    torch.manual_seed(0)
+    B, N, T = 2048, 4, 160
+    env = SkyjoVecEnv(B, num_players=N, reward_refunded=0.0)
+    env.seed(None, 21)
+    env.reset()
+    model = ActionMaskModel(obs_dim=env.obs_dim).cuda()
+    pol, val = FusedNet(model.policy), FusedNet(model.value)
+    buf = RolloutBuffer(env, T)
+    for rnd in range(3):
+        collect(env, pol, val, buf, seed=5, first_ticket=rnd * T)
+        v = buf.views(env)
+        a = buf.actions.long()
+        assert bool(v.action_mask[:T].gather(2, a.unsqueeze(-1)).eq(1).all())      # legal under the stored masks
+        assert bool((v.agent[:T] < N).all())
+        # stored log-probabilities against a recomputation from the stored records
+        t = T // 2
+        logits = pol(buf.records[t])
+        mask = v.action_mask[t].float()
+        ref = torch.log_softmax(logits + torch.clamp(torch.log(mask), min=torch.finfo(torch.float32).min), -1)
+        assert float((ref.gather(1, a[t].unsqueeze(1)).squeeze(1) - buf.logp[t]).abs().max()) < 1e-5
+        assert float((val(buf.records[t]) - buf.values[t]).abs().max()) == 0.0
+        ends = buf.episode_end
+        if rnd == 2:
+            assert int(ends.sum()) > 0
+        rw = buf.final_rewards[ends]                                               # [episodes, N]
+        assert bool(((rw.sum(-1) - N * 1.0).abs() < 1e-9).all())                    # skyjo_env.py:307-312
+        assert bool((buf.final_rewards[~ends] == 0).all())
+    assert env.counters()["illegal"] == 0
+    env.close()
