@@ -180,7 +180,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg,
                          "deal_kernel_avg_ms": prof["deal_ms"] / max(prof["deal_launches"], 1)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: a reported baseline, not part of the scaling runs)
             out["cpu_baseline"] = cpu_baseline(N)
         print(json.dumps(out), flush=True)
     eng.close()
