@@ -148,7 +148,7 @@ def main():
     achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
-    if os.path.exists(tpath) and B == 65536 and N == 3 and record:
+    if os.path.exists(tpath) and B == 65536 and N == 3 and record and CHUNK == 80:  # (the PMC passes ran this very launch shape)
         traffic = json.load(open(tpath)).get("k_step_bytes_per_launch")
 
     if rank == 0:
