@@ -123,13 +123,18 @@ int start_deals(skyjo_vec *h, hipStream_t s) {
     const uint32_t tag = hh[1], empty = hh[0];
     if (tag != h->health_seen) {  // the report of a run that has finished since the last look (one or two runs old)
       h->health_seen = tag;
-      if (empty) {
+      // An empty bank at scan time is a warning (one more game end before the next run deals in place), not yet a
+      // stall: a handful of them is tolerated, one game in a thousand is not.
+      const uint32_t many = (uint32_t)(h->P.B / 1024 > 1 ? h->P.B / 1024 : 1);
+      if (empty >= many) {
         const int cut = h->deal_every_iters / 8 > 4 ? h->deal_every_iters / 8 : 4;
         h->deal_every_iters = h->deal_every_iters - cut > 8 ? h->deal_every_iters - cut : 8;
         h->calm_runs = 0;
-      } else if (++h->calm_runs >= 32 && h->deal_every_iters < h->interval_default) {
+      } else if (empty) {
+        h->calm_runs = 0;
+      } else if (++h->calm_runs >= 8 && h->deal_every_iters < h->interval_default) {
         h->deal_every_iters += 2;
-        h->calm_runs = 16;
+        h->calm_runs = 0;
       }
     }
   }
