@@ -114,7 +114,7 @@ int publish_deals(skyjo_vec *h, hipStream_t s) {
 
 // One dealing cycle: publish the previous one, list the banks that are not full, deal one episode for each.
 // With overlap on, k_deal runs on its own stream beside the k_step launches that follow; its episodes are
-// published at the start of the next cycle (64 iterations later), long before a bank of SK_BANK runs dry.
+// published at the start of the next cycle (one dealing interval later), long before a bank of SK_BANK runs dry.
 int start_deals(skyjo_vec *h, hipStream_t s) {
   int rc;
   if ((rc = publish_deals(h, s))) return rc;

@@ -386,7 +386,7 @@ __device__ __forceinline__ void reshuffle_discard(const SkParams &P, uint8_t *lp
 // While a dealing launch overlaps this kernel, the games it deals for are marked busy: it owns their RNG stream
 // and one bank slot.  The rare paths that need the stream wait for that one deal to finish (the dealing launch
 // never waits for anybody, so this cannot deadlock; the spin is bounded all the same).
-// Returns true when that deal gave itself up (undo log overrun): it then left no record and no trace in the stream.
+// Returns true when that deal gave itself up (close to a full turn of the generator state, see k_deal): it then left no record and no trace in the stream.
 __device__ __forceinline__ bool wait_deal_done(const SkParams &P, int g) {
   uint32_t f = 0;
   for (int spin = 0; spin < (1 << 22); spin++) {
@@ -1626,7 +1626,7 @@ __device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint
 }
 
 // ------------------------------------------------------------------------------------------
-// Dealing pipeline, once per 64 lockstep iterations:
+// Dealing pipeline, once per dealing interval (80 lockstep iterations by default for three and more players):
 //   k_scan    (caller's stream)  finds the banks that are not full with a wavefront ballot + prefix popcount,
 //                                appends (game, episode) to the work list and marks the games busy;
 //   k_deal    (own stream, may overlap the following k_step launches) deals one episode per listed game,
