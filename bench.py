@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--rng", choices=["mt19937", "philox"], default="mt19937")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-records", action="store_true", help="do not write records/actions (not the headline)")
+    ap.add_argument("--direct-obs", action="store_true", help="observe_other_player_indirect=False: D = 19 + 12 N (not the headline)")
     args = ap.parse_args()
 
     import torch
@@ -91,7 +92,7 @@ def main():
     global CHUNK
     if N < 3:
         CHUNK = min(CHUNK, 64)  # the engine deals every 64 iterations below three players (shorter episodes)
-    eng = SkyjoVecEnv(B, num_players=N, score_penalty=2.0, observe_other_player_indirect=True, mean_reward=1.0,
+    eng = SkyjoVecEnv(B, num_players=N, score_penalty=2.0, observe_other_player_indirect=not args.direct_obs, mean_reward=1.0,
                       reward_refunded=0.001, device=local_rank,
                       rng_mode=RNG_MT19937 if args.rng == "mt19937" else RNG_PHILOX, auto_reset=True,
                       game_id0=rank * B)  # shards by global game id: results do not depend on the GPU count
@@ -167,7 +168,7 @@ def main():
             "dtype": "int8",
             "data": "synthetic",
             "config": {"workload": f"{B} parallel {N}-player games per GPU, random admissible policy on device, "
-                                   f"DEFAULT_CONFIG (indirect obs D={D}), auto-reset, records+actions written every step"
+                                   f"{'direct' if args.direct_obs else 'DEFAULT_CONFIG (indirect'} obs D={D}{'' if args.direct_obs else ')'}, auto-reset, records+actions written every step"
                                    if record else f"{B} x {N}-player games per GPU, no records",
                        "games_per_gpu": B, "num_players": N, "rng_mode": args.rng,
                        "iterations_per_launch": CHUNK, "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},

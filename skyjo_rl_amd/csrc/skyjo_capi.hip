@@ -248,7 +248,8 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   P.game_id0 = cfg->game_id0;
   h->G = (size_t)P.tiles * SK_TILE;
   h->lds_tile = (size_t)P.L.chunks * 1024;
-  h->lds_bytes = h->lds_tile + 4096 + 2 * (size_t)cfg->num_players * 512 + 4096;  // tile + 16-word RNG scratch + float64 sums + one iteration's records
+  // tile + 16-word RNG scratch + float64 sums + one iteration's records (64 B each, or rec_bytes (+16) for the direct observation)
+  h->lds_bytes = h->lds_tile + 4096 + 2 * (size_t)cfg->num_players * 512 + (size_t)SK_TILE * (P.L.indirect ? 64 : P.L.rec_bytes + 16);
   const size_t rec16 = (size_t)P.tiles * P.L.chunks * SK_TILE;
   int rc = SKYJO_OK;
   const size_t N = (size_t)cfg->num_players;

@@ -903,6 +903,9 @@ __device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, in
 // The same in two halves for the step kernel (compile-time chunk count): `spare_issue` requests the whole
 // record, `spare_commit` lands it.  Between the two the wavefront steps its live games, which hides the
 // HBM round trip of the few lanes that are resetting (about every second iteration has one).
+// LDS stride of one staged record: the record's own size, plus 16 bytes when that is a multiple of 32 dwords / 4 - the
+// lane-per-record dword writes then spread over 8 banks groups instead of 4.
+__device__ __forceinline__ constexpr int sk_stage_stride(int rec_bytes) { return ((rec_bytes >> 2) & 7) == 0 ? rec_bytes + 16 : rec_bytes; }
 constexpr int sk_chunks_of(int N) { return ((((H_END + 6 * N + 3) & ~3) + 24 * N + SK_NCARDS + 15) & ~15) / 16; }
 template <int CH>
 struct SpareRegs {
@@ -1017,8 +1020,8 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
           emit_record<INDIRECT>(P, lp, h, ob, nullptr, rr);
 #pragma unroll
           for (int p = 0; p < 4; p++) *(uint4 *)(stg + lane * 64 + ((p + (lane >> 1)) & 3) * 16) = rr[p];
-        } else {
-          emit_record<INDIRECT>(P, lp, h, ob, rec_out + ((size_t)it * P.B + g) * (size_t)P.L.rec_bytes);
+        } else {  // direct observation: rec_bytes = 80 / 96 / 112 ...; staged record-major with a stride that spreads the banks
+          emit_record<INDIRECT>(P, lp, h, ob, stg + lane * sk_stage_stride(P.L.rec_bytes));
         }
       }
       if (act_out) __builtin_nontemporal_store(a, &act_out[(size_t)it * P.B + g]);
@@ -1027,6 +1030,17 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
 #else
       STAMP(6);
 #endif
+    }
+    if (!INDIRECT && rec_out) {  // same idea for the wider records of the direct observation: rec_bytes / 16 pieces each
+      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+      const int pieces = P.L.rec_bytes >> 4, stride = sk_stage_stride(P.L.rec_bytes);
+      uint8_t *blk = rec_out + ((size_t)it * P.B + (size_t)tile * SK_TILE) * (size_t)P.L.rec_bytes;
+      const int live = P.B - tile * SK_TILE;
+      for (int q = lane; q < pieces * SK_TILE; q += SK_TILE) {  // piece q of the tile's block: record q / pieces, piece q % pieces
+        const int r = q / pieces, p = q - r * pieces;
+        const uint4 v = *(const uint4 *)(stg + r * stride + p * 16);
+        if (r < live) __builtin_nontemporal_store((u32x4_t){v.x, v.y, v.z, v.w}, (u32x4_t *)(blk + (size_t)q * 16));
+      }
     }
     if (INDIRECT && rec_out) {
       // The 64 records of the tile are one contiguous 4 KiB block of the output.  They pass through LDS so that each
