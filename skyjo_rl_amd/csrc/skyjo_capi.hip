@@ -382,8 +382,7 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
   uint8_t *rec = (uint8_t *)records_out;
   for (int done = 0; done < iters;) {
     int n = iters - done < kMaxRolloutChunk ? iters - done : kMaxRolloutChunk;
-    const int until_deal = h->deal_every_iters - h->pending_iters;  // (a launch never runs past the next dealing run)
-    if (until_deal >= 1 && n > until_deal) n = until_deal;
+    if (n > h->deal_every_iters) n = h->deal_every_iters;  // (a launch is never longer than the dealing interval in force)
     int rc = launch_step(h, s, true, nullptr, rec, actions_out, n, policy_seed);
     if (rc) return rc;
     done += n;
