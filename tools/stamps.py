@@ -7,7 +7,7 @@ from skyjo_rl_amd import SkyjoVecEnv, _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 eng = SkyjoVecEnv(B, num_players=3)
 eng.seed(None, 0)
-ITERS = 32
+ITERS = 80
 rec = eng.new_records(ITERS); act = torch.empty((ITERS, B), dtype=torch.int32, device="cuda")
 if len(sys.argv) > 2 and sys.argv[2] == "norec": rec = act = None
 for _ in range(20): eng.rollout(ITERS, 1, records=rec, actions=act)
