@@ -228,6 +228,11 @@ int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, co
 int skyjo_vec_mlp_destroy(skyjo_vec_mlp *m);
 int skyjo_vec_mlp_forward(const skyjo_vec_mlp *m, const void *records, int32_t record_bytes, int64_t n, float *out,
                           void *stream);
+/* Policy branch (out_dim == 26) and the draw of skyjo_vec_sample_actions in ONE launch: the logits never leave the
+ * registers (logits_out, float32 [n][26], may be NULL).  Same (seed, ticket) -> the same actions as
+ * skyjo_vec_mlp_forward followed by skyjo_vec_sample_actions, bit for bit. */
+int skyjo_vec_mlp_act(skyjo_vec *h, const skyjo_vec_mlp *m, const void *records, int64_t n, uint64_t seed, uint64_t ticket,
+                      int32_t no_masking, int32_t *actions_out, float *logp_out, float *logits_out, void *stream);
 
 /* host-pointer conveniences for small batches (single-game AEC view): synchronous */
 int skyjo_vec_step_host(skyjo_vec *h, const int32_t *actions_host, void *records_out_host);

@@ -67,6 +67,7 @@ SIGNATURES = {
     "skyjo_vec_mlp_create": (C.c_int, [I32, I32, I32, VP, VP, VP, VP, VP, VP, C.POINTER(VP)]),
     "skyjo_vec_mlp_destroy": (C.c_int, [VP]),
     "skyjo_vec_mlp_forward": (C.c_int, [VP, VP, I32, I64, VP, VP]),
+    "skyjo_vec_mlp_act": (C.c_int, [VP, VP, VP, I64, U64, U64, I32, VP, VP, VP, VP]),
     "skyjo_vec_rewards_ptr": (VP, [VP]),
     "skyjo_vec_scores_ptr": (VP, [VP]),
     "skyjo_vec_done_ptr": (VP, [VP]),

@@ -97,6 +97,18 @@ class FusedNet:
                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return out
 
+    def act(self, env, records, seed=0, ticket=0, no_masking=False, actions=None, logp=None, logits=None):
+        """Policy branch + masked categorical draw in one launch (``skyjo_vec_mlp_act``): int32 actions for ``env.step``."""
+        n = records.numel() // records.shape[-1]
+        if actions is None:
+            actions = torch.empty((n,), dtype=torch.int32, device=records.device)
+        C = self._C
+        vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self._check(self._L.skyjo_vec_mlp_act(env._h, self._h, vp(records), n, int(seed), int(ticket), 1 if no_masking else 0,
+                                              vp(actions), vp(logp), vp(logits),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return actions
+
     def close(self):
         if self._h:
             self._L.skyjo_vec_mlp_destroy(self._h)

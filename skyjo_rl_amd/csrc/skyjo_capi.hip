@@ -511,8 +511,23 @@ int skyjo_vec_mlp_forward(const skyjo_vec_mlp *m, const void *records, int32_t r
   if (!m || !records || !out || n < 0 || record_bytes < 32 || (record_bytes & 15))
     return fail(SKYJO_E_INVALID, "skyjo_vec_mlp_forward: bad argument");
   if (n == 0) return SKYJO_OK;
+  SkMlpDraw nodraw{};
   hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT - 1) / (32 * SKP_GT))), dim3(64), 0, (hipStream_t)stream, m->net,
-                     (const uint8_t *)records, (int)record_bytes, m->obs_dim, (long long)n, out);
+                     (const uint8_t *)records, (int)record_bytes, m->obs_dim, (long long)n, out, nodraw);
+  HIPCHK(hipGetLastError());
+  return SKYJO_OK;
+}
+
+int skyjo_vec_mlp_act(skyjo_vec *h, const skyjo_vec_mlp *m, const void *records, int64_t n, uint64_t seed, uint64_t ticket,
+                      int32_t no_masking, int32_t *actions_out, float *logp_out, float *logits_out, void *stream) {
+  if (!h || !m || !records || !actions_out || n < 0) return fail(SKYJO_E_INVALID, "skyjo_vec_mlp_act: bad argument");
+  if (m->net.out_dim != SKYJO_NUM_ACTIONS) return fail(SKYJO_E_INVALID, "skyjo_vec_mlp_act needs a net with 26 outputs");
+  if (n == 0) return SKYJO_OK;
+  SkMlpDraw d{};
+  d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = ticket;
+  d.game_id0 = h->P.game_id0, d.actions = actions_out, d.logp = logp_out;
+  hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT - 1) / (32 * SKP_GT))), dim3(64), 0, (hipStream_t)stream, m->net,
+                     (const uint8_t *)records, (int)h->P.L.rec_bytes, m->obs_dim, (long long)n, logits_out, d);
   HIPCHK(hipGetLastError());
   return SKYJO_OK;
 }

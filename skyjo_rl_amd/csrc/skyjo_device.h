@@ -1859,6 +1859,45 @@ __global__ void k_reduce_stats(SkParams P) {
 // stretch that is copied to LDS with coalesced 16-byte loads; a lane then walks its own row (stride 26 words:
 // two lanes per bank).  The mask bytes come straight out of the engine's records.
 // ------------------------------------------------------------------------------------------
+// One game's draw: masked = logits + clamp(log(mask), FLOAT_MIN) (action_mask_model.py:70-71), softmax, inverse CDF of
+// the Philox uniform of (seed, ticket, game).  Shared by k_sample and by the policy net's epilogue (skyjo_policy.h).
+__device__ __forceinline__ int sk_draw_action(const float *row, const uint32_t *mw, int no_masking, uint64_t seed, uint64_t ticket,
+                                              uint64_t gid, float *logp_out, float *uniform_out) {
+  const float FLOAT_MIN = -3.4028234663852886e38f;  // torch.finfo(float32).min == ray's FLOAT_MIN
+  float m[SKYJO_NUM_ACTIONS], mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < SKYJO_NUM_ACTIONS; k++) {
+    const bool on = no_masking || ((mw[k >> 2] >> ((k & 3) * 8)) & 0xffu) != 0;
+    m[k] = on ? row[k] : row[k] + FLOAT_MIN;  // log(1) = 0, clamp(log(0)) = FLOAT_MIN
+    mx = fmaxf(mx, m[k]);
+  }
+  float e[SKYJO_NUM_ACTIONS], sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < SKYJO_NUM_ACTIONS; k++) e[k] = __expf(m[k] - mx), sum += e[k];
+  uint32_t u0, u1, u2, u3;
+  philox4x32_10((uint32_t)ticket, (uint32_t)(ticket >> 32), (uint32_t)gid, 0x53414D50u ^ (uint32_t)(gid >> 32), (uint32_t)seed,
+                (uint32_t)(seed >> 32), u0, u1, u2, u3);
+  const float u = (float)(u0 >> 8) * (1.0f / 16777216.0f);  // 24 bits -> [0, 1)
+  const float target = u * sum;
+  float acc = 0.f;
+  int a = -1, last_on = 0;
+#pragma unroll
+  for (int k = 0; k < SKYJO_NUM_ACTIONS; k++) {
+    acc += e[k];
+    last_on = e[k] > 0.f ? k : last_on;
+    a = (a < 0 && acc > target) ? k : a;
+  }
+  a = a < 0 ? last_on : a;  // (rounding at the very top of the distribution)
+  if (logp_out) {
+    float ma = m[0];
+#pragma unroll
+    for (int k = 1; k < SKYJO_NUM_ACTIONS; k++) ma = a == k ? m[k] : ma;
+    *logp_out = (ma - mx) - __logf(sum);
+  }
+  if (uniform_out) *uniform_out = u;
+  return a;
+}
+
 #define SK_SAMPLE_BLOCK 256
 __global__ __launch_bounds__(SK_SAMPLE_BLOCK) void k_sample(SkLayout L, const uint8_t *rec, const float *logits, long long n,
                                                             uint64_t seed, uint64_t ticket, uint64_t game_id0, int no_masking,
@@ -1884,40 +1923,10 @@ __global__ __launch_bounds__(SK_SAMPLE_BLOCK) void k_sample(SkLayout L, const ui
 #pragma unroll
   for (int k = 0; k < 7; k++) mw[k] = ((const uint32_t *)r)[k];
   const float *row = rows + threadIdx.x * SKYJO_NUM_ACTIONS;
-  const float FLOAT_MIN = -3.4028234663852886e38f;  // torch.finfo(float32).min == ray's FLOAT_MIN
-  float m[SKYJO_NUM_ACTIONS], mx = -INFINITY;
-#pragma unroll
-  for (int k = 0; k < SKYJO_NUM_ACTIONS; k++) {
-    const bool on = no_masking || ((mw[k >> 2] >> ((k & 3) * 8)) & 0xffu) != 0;
-    m[k] = on ? row[k] : row[k] + FLOAT_MIN;  // log(1) = 0, clamp(log(0)) = FLOAT_MIN
-    mx = fmaxf(mx, m[k]);
-  }
-  float e[SKYJO_NUM_ACTIONS], sum = 0.f;
-#pragma unroll
-  for (int k = 0; k < SKYJO_NUM_ACTIONS; k++) e[k] = __expf(m[k] - mx), sum += e[k];
-  uint32_t u0, u1, u2, u3;
-  const uint64_t gid = game_id0 + (uint64_t)g;
-  philox4x32_10((uint32_t)ticket, (uint32_t)(ticket >> 32), (uint32_t)gid, 0x53414D50u ^ (uint32_t)(gid >> 32), (uint32_t)seed,
-                (uint32_t)(seed >> 32), u0, u1, u2, u3);
-  const float u = (float)(u0 >> 8) * (1.0f / 16777216.0f);  // 24 bits -> [0, 1)
-  const float target = u * sum;
-  float acc = 0.f;
-  int a = -1, last_on = 0;
-#pragma unroll
-  for (int k = 0; k < SKYJO_NUM_ACTIONS; k++) {
-    acc += e[k];
-    last_on = e[k] > 0.f ? k : last_on;
-    a = (a < 0 && acc > target) ? k : a;
-  }
-  a = a < 0 ? last_on : a;  // (rounding at the very top of the distribution)
-  actions[g] = a;
-  if (logp) {
-    float ma = m[0];
-#pragma unroll
-    for (int k = 1; k < SKYJO_NUM_ACTIONS; k++) ma = a == k ? m[k] : ma;
-    logp[g] = (ma - mx) - __logf(sum);
-  }
-  if (uniform) uniform[g] = u;
+  float lp_ = 0.f, u_ = 0.f;
+  actions[g] = sk_draw_action(row, mw, no_masking, seed, ticket, game_id0 + (uint64_t)g, logp ? &lp_ : nullptr, &u_);
+  if (logp) logp[g] = lp_;
+  if (uniform) uniform[g] = u_;
 }
 
 // records -> the reference's dense arrays (obs int8[n][D], mask int8[n][26], ...)

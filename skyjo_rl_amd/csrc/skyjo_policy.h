@@ -24,6 +24,15 @@
 typedef __bf16 skp_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float skp_f32x16 __attribute__((ext_vector_type(16)));
 
+// Optional epilogue of the policy branch: the masked categorical draw of k_sample on the logits that have just been
+// computed, without their round trip through memory.
+struct SkMlpDraw {
+  int enable, mask_offset, no_masking;
+  uint64_t seed, ticket, game_id0;
+  int32_t *actions;
+  float *logp;
+};
+
 struct SkMlpDev {
   const uint4 *w1;   // [8 m-tiles][2 k-steps][64 lanes] fragments, natural k order (k = feature)
   const uint4 *w2;   // [8][16][64] fragments, accumulator k order
@@ -55,7 +64,7 @@ __device__ __forceinline__ skp_bf16x8 skp_frag(const uint4 *p) {
 // rec_bytes / obs_dim as in the engine's records (indirect observation: 31 int8 features).
 #define SKP_GT 1  // (2: 47.7 us vs 42.7 us per 65 536 records - the kernel is bound by its 512 tanh per game, not by weight traffic)
 __global__ __launch_bounds__(64) void k_mlp_forward(SkMlpDev net, const uint8_t *rec, int rec_bytes, int obs_dim, long long n,
-                                                     float *out) {
+                                                     float *out, SkMlpDraw draw) {
   const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
   long long g[SKP_GT];
   skp_bf16x8 x[SKP_GT][2];
@@ -148,12 +157,34 @@ __global__ __launch_bounds__(64) void k_mlp_forward(SkMlpDev net, const uint8_t 
     for (int c = 0; c < SKP_GT; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, h2[c][ks], acc[c], 0, 0, 0);
   }
 #pragma unroll
-  for (int c = 0; c < SKP_GT; c++)
-    if (g[c] < n) {
+  for (int c = 0; c < SKP_GT; c++) {
+    if (out && g[c] < n) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < net.out_dim) out[g[c] * net.out_dim + row] = acc[c][r];
       }
     }
+    if (draw.enable) {
+      // a game's 32 outputs sit in two lanes (this one and lane ^ 32: rows 4h .. 4h+3 of every block of 8): swap halves
+      float full[32];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float other = __shfl_xor(acc[c][r], 32, 64);
+        const int blk8 = r >> 2, i4 = r & 3;
+        full[8 * blk8 + i4] = h ? other : acc[c][r];      // rows 0..3 of the block belong to the h = 0 lane
+        full[8 * blk8 + 4 + i4] = h ? acc[c][r] : other;  // rows 4..7 to the h = 1 lane
+      }
+      if (h == 0 && g[c] < n) {
+        const uint32_t *mp = (const uint32_t *)(rec + g[c] * rec_bytes + draw.mask_offset);
+        uint32_t mw[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) mw[k] = mp[k];
+        float lp = 0.f;
+        draw.actions[g[c]] = sk_draw_action(full, mw, draw.no_masking, draw.seed, draw.ticket, draw.game_id0 + (uint64_t)g[c],
+                                            draw.logp ? &lp : nullptr, nullptr);
+        if (draw.logp) draw.logp[g[c]] = lp;
+      }
+    }
+  }
 }

@@ -20,7 +20,6 @@ class RolloutBuffer:
         self.actions = torch.empty((T, B), dtype=torch.int32, device=dev)
         self.logp = torch.empty((T, B), dtype=torch.float32, device=dev)
         self.values = torch.empty((T + 1, B, 1), dtype=torch.float32, device=dev)
-        self.logits = torch.empty((B, 26), dtype=torch.float32, device=dev)
         self.final_rewards = torch.zeros((T, B, N), dtype=torch.float64, device=dev)  # non-zero rows where episode_end[t]
         self.episode_end = torch.zeros((T, B), dtype=torch.bool, device=dev)
 
@@ -41,9 +40,8 @@ def collect(env, policy, value, buf, seed=0, first_ticket=0, first_records=None)
         buf.records[0].copy_(first_records)
     for t in range(T):
         rec = buf.records[t]
-        policy(rec, out=buf.logits)
+        policy.act(env, rec, seed=seed, ticket=first_ticket + t, actions=buf.actions[t], logp=buf.logp[t])
         value(rec, out=buf.values[t])
-        env.sample_actions(buf.logits, rec, seed=seed, ticket=first_ticket + t, actions=buf.actions[t], logp=buf.logp[t])
         env.step(buf.actions[t], out=buf.records[t + 1])
         v = env.split(buf.records[t + 1])
         # a game that has just ended shows done = 1 in the record written by this step; its rewards stay valid until the

@@ -82,3 +82,29 @@ def test_fused_policy_loop_plays_legal_games():
     c = env.counters()
     assert c["illegal"] == 0 and c["episodes"] > 0
     env.close()
+
+
+def test_act_equals_forward_then_sample_bit_for_bit():
+    import torch
+
+    from skyjo_rl_amd import SkyjoVecEnv
+    from skyjo_rl_amd.action_mask_model import ActionMaskModel, FusedNet
+
+    torch.manual_seed(2)
+    B = 5000  # (not a multiple of 32: the last wavefront is partly empty)
+    env = SkyjoVecEnv(B, num_players=3)
+    env.seed(None, 8)
+    model = ActionMaskModel(obs_dim=env.obs_dim).cuda()
+    pol = FusedNet(model.policy)
+    rec = env.reset()
+    for t in range(40):
+        logits = pol(rec)
+        lp_a = torch.empty(B, device="cuda")
+        a_ref = env.sample_actions(logits, rec, seed=3, ticket=t, logp=lp_a)
+        lp_b = torch.empty(B, device="cuda")
+        lg = torch.empty((B, 26), device="cuda")
+        a = pol.act(env, rec, seed=3, ticket=t, logp=lp_b, logits=lg)
+        assert torch.equal(a, a_ref) and torch.equal(lp_a, lp_b) and torch.equal(lg, logits)
+        rec = env.step(a)
+    assert env.counters()["illegal"] == 0
+    env.close()

@@ -24,11 +24,11 @@ for dtype in (torch.float32, torch.bfloat16):
         rec = env.reset()
         gen = torch.Generator(device="cuda").manual_seed(1)
         pol = FusedNet(model.policy) if form == "mfma" else None
-        logits_buf = torch.empty((B, 26), dtype=torch.float32, device="cuda")
+        act_buf = torch.empty((B,), dtype=torch.int32, device="cuda")
 
         def one(t, rec):
-            if form == "mfma":  # policy net on the matrix cores (skyjo_vec_mlp_forward) + fused draw + env step: 3 launches
-                return env.step(env.sample_actions(pol(rec, out=logits_buf), rec, seed=9, ticket=t), out=rec)
+            if form == "mfma":  # policy net on the matrix cores with the draw in its epilogue (skyjo_vec_mlp_act) + env step: 2 launches
+                return env.step(pol.act(env, rec, seed=9, ticket=t, actions=act_buf), out=rec)
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
                 if form == "torch":
                     v = env.split(rec)
