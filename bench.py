@@ -56,7 +56,16 @@ def cpu_baseline(num_players, seconds=12.0):
         iters += 32
     dt = time.perf_counter() - t0
     steps = ora.counters()["steps"] - s0
-    return {"value": steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+    # the same port on ONE host thread (SURVEY 8d asks for both), a few seconds
+    one = so.OracleVec(num_envs=4096, num_players=num_players, score_penalty=2.0, observe_other_player_indirect=True,
+                       mean_reward=1.0, reward_refunded=0.001, rng_mode=so.RNG_MT19937, auto_reset=True)
+    one.seed(None, 0)
+    one.rollout(8, 1, threads=1)
+    s1, t1 = one.counters()["steps"], time.perf_counter()
+    while time.perf_counter() - t1 < 3.0:
+        one.rollout(16, 1, threads=1)
+    single = (one.counters()["steps"] - s1) / (time.perf_counter() - t1)
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port", "value_1_thread": single,
             "sample": f"{B} games x {iters} lockstep iterations ({steps} env-steps, {dt:.1f} s), "
                       f"oracle/skyjo_oracle.c with OpenMP over games, same on-device-policy restatement"}
 
