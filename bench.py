@@ -73,8 +73,8 @@ def cpu_baseline(num_players, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=20000)   # 57 ms of GPU time at 2.8 us per lockstep iteration: short enough to
+    ap.add_argument("--warmup", type=int, default=2000)   # finish at once, long enough that the first launches after the barrier do not show
     ap.add_argument("--num-envs", type=int, default=65536, help="games per GPU")
     ap.add_argument("--num-players", type=int, default=3)
     ap.add_argument("--rng", choices=["mt19937", "philox"], default="mt19937")
