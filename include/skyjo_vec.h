@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SKYJO_ABI_VERSION 1
+#define SKYJO_ABI_VERSION 2
 #define SKYJO_MAX_PLAYERS 12 /* skyjo.py:24-26 */
 #define SKYJO_NUM_ACTIONS 26 /* skyjo.py:46 */
 #define SKYJO_NUM_CARDS 150  /* skyjo.py:80 */
@@ -53,6 +53,10 @@ extern "C" {
 #define SKYJO_ST_NOOP_DONE 2 /* game already over and auto_reset off (skyjo.py:316-321) */
 #define SKYJO_ST_RESET 3     /* game was over: a new episode was dealt, the action was ignored */
 #define SKYJO_ST_WAIT 4      /* reserved (never produced: a missing pre-dealt episode is dealt in place) */
+
+/* skyjo_vec_step: a game whose action is SKYJO_ACTION_SKIP is left exactly as it is (no step, no reset; its record is
+ * still written) - the single-game views use it to step ONE game of a shared engine (SkyjoGame(engine=, index=)). */
+#define SKYJO_ACTION_SKIP (-1000)
 
 /* RNG modes */
 #define SKYJO_RNG_MT19937 0 /* numpy legacy stream, bit-identical deals to the reference */
@@ -78,6 +82,9 @@ typedef struct skyjo_vec_config {
 
 /* Output record: one per game per step, `record_bytes` long (64 for the indirect observation):
  *   [0, D)            int8 observations            (skyjo.py:180-190)
+ *   [D]               int8 the action the step that wrote this record applied to the game (-1: none - the game was
+ *                     reset / already over / skipped, or the record comes from reset / observe); D is odd, so the
+ *                     byte is the padding between the observation and the mask
  *   [Dp, Dp+26)       int8 action_mask, Dp = (D+3)&~3 (skyjo.py:201-224)
  *   [Dp+26]           expected player (agent id)   (skyjo.py:503)
  *   [Dp+27]           phase 0 = draw, 1 = place
@@ -98,8 +105,10 @@ typedef struct skyjo_vec_counters {
   uint64_t reshuffles;
   uint64_t iters;    /* lockstep iterations executed */
   uint64_t waits;    /* deals made on the in-kernel slow path (pre-dealt episode not available) */
-  double sum_score[SKYJO_MAX_PLAYERS];  /* per seat, finished episodes */
-  double sum_reward[SKYJO_MAX_PLAYERS]; /* per seat, finished + illegal episodes */
+  double sum_score[SKYJO_MAX_PLAYERS];     /* per seat, finished episodes (skyjo.py:59) */
+  double sum_reward[SKYJO_MAX_PLAYERS];    /* per seat, finished + illegal episodes (skyjo_env.py:293-312) */
+  double sum_reward_sq[SKYJO_MAX_PLAYERS]; /* per seat, squares of the same rewards */
+  double sum_refunded[SKYJO_MAX_PLAYERS];  /* per seat, num_refunded of finished episodes (skyjo.py:57) */
 } skyjo_vec_counters;
 
 /* Canonical per-game state (debug, fixtures, snapshot/restore).  Field names follow skyjo.py. */
@@ -137,6 +146,9 @@ int skyjo_vec_get_info(const skyjo_vec *h, skyjo_vec_info *out);
  * base_seed + game_id0 + i when seeds_host is NULL; the legacy stream is seeded with value+1 and
  * the first deal is made immediately, exactly like set_seed.  Must precede every other call. */
 int skyjo_vec_seed(skyjo_vec *h, const uint64_t *seeds_host, uint64_t base_seed, void *stream);
+/* SkyjoGame.set_seed (skyjo.py:84-88) for ONE game of the batch: its stream is re-seeded with value + 1, its bank of
+ * pre-dealt episodes is dealt again and the first deal becomes the live game.  The other games are untouched. */
+int skyjo_vec_seed_one(skyjo_vec *h, int32_t game, uint64_t value, void *stream);
 
 /* SkyjoGame.reset / SimpleSkyjoEnv.reset (skyjo.py:52-74, skyjo_env.py:254-267) for the games whose
  * mask byte is non-zero (all when mask is NULL).  records_out (may be NULL): [num_envs][record_bytes]. */
@@ -149,7 +161,8 @@ int skyjo_vec_step(skyjo_vec *h, const int32_t *actions, void *records_out, void
 /* `iters` lockstep iterations in one launch with the uniform random admissible policy
  * (rlskyjo/models/random_admissible_policy.py:6-28) evaluated on device.
  * records_out: NULL, or [iters][num_envs][record_bytes] (record AFTER each iteration);
- * actions_out: NULL, or int32[iters][num_envs] (-1 where no action was applied). */
+ * actions_out: NULL, or int32[iters][num_envs] (-1 where no action was applied) - the same value is byte D of every
+ * record, so a caller that keeps the records does not need this array. */
 int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *records_out, int32_t *actions_out,
                       void *stream);
 
@@ -174,12 +187,22 @@ int skyjo_vec_set_state(skyjo_vec *h, int32_t game, const skyjo_game_state *in_h
 /* np.random.seed(value) on one game's legacy stream without dealing (fixture injection) */
 int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream);
 
-/* Kernel timing with HIP events on the launch stream: while enabled, every step / dealing kernel is launched
- * with a (start, stop) event pair that receives the kernel's own begin and end timestamps.  Returns and clears
- * what was collected since the last call (sum of milliseconds and launch counts per kernel), then switches
- * collection on (1) or off (0).  Synchronises the device. */
-int skyjo_vec_profile(skyjo_vec *h, int enable, double *step_ms, int64_t *step_launches, double *deal_ms,
-                      int64_t *deal_launches);
+/* Kernel timing with HIP events on the launch stream: while enabled, every kernel of the path is launched with a
+ * (start, stop) event pair that receives the kernel's own begin and end timestamps.  Returns and clears what was
+ * collected since the last call - sum of milliseconds and launch count per kernel: [0] k_step, [1] k_scan, [2] k_deal,
+ * [3] k_publish - then switches collection on (1) or off (0).  Synchronises the device. */
+#define SKYJO_PROF_KERNELS 4
+int skyjo_vec_profile(skyjo_vec *h, int enable, double ms_out[SKYJO_PROF_KERNELS], int64_t launches_out[SKYJO_PROF_KERNELS]);
+
+/* Snapshot / restore of the WHOLE engine (the reference has no such feature): every live game, every bank
+ * of pre-dealt episodes, every RNG stream with its position, statistics and the policy counter.  A snapshot lives in
+ * device memory owned by the library; restoring it into the handle it was taken from makes every later call produce
+ * exactly what it produced after the snapshot was taken.  Both calls drain the dealing pipeline and synchronise. */
+typedef struct skyjo_vec_snapshot skyjo_vec_snapshot; /* opaque */
+int skyjo_vec_snapshot_create(skyjo_vec *h, skyjo_vec_snapshot **out, void *stream);
+int skyjo_vec_snapshot_restore(skyjo_vec *h, const skyjo_vec_snapshot *snap, void *stream);
+int skyjo_vec_snapshot_bytes(const skyjo_vec_snapshot *snap, size_t *bytes_out);
+int skyjo_vec_snapshot_destroy(skyjo_vec_snapshot *snap);
 
 /* Diagnostic builds only (-DSK_STAMPS): per-section shader-cycle sums, 8 for the step kernel followed by 8 for
  * the dealing kernel, summed over wavefronts, cleared on read.  The shipped build returns zeros. */

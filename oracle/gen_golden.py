@@ -20,6 +20,8 @@ inputs -> outputs of the hot path:
   env_*.npz        SimpleSkyjoEnv (skyjo_env.py:29-334) driven through pettingzoo STAND-INS
                    ("wrapper semantics unpinned"): obs / rewards / dones per agent_iter turn,
                    including the TerminateIllegalWrapper flow
+  render.npz       the text the reference's render utils print (skyjo.py:508-602) for fresh,
+                   mid-game, collapsed-column, empty-discard and terminated states
 
 The fixtures are data (inputs and expected outputs) - no reference source text is stored.
 """
@@ -426,7 +428,87 @@ def gen_env(cfg, seed, name, illegal_at=None, illegal_action=None, episodes=2):
     return len(rows["agent"])
 
 
+def render_strings(g):
+    """Everything the reference can print about one state (skyjo.py:508-562)."""
+    N = g.num_players
+    return (g.render_table(), [g.render_player(p) for p in range(N)], [g.render_player(p, True) for p in range(N)])
+
+
+def gen_render():
+    """Render fixtures: strings produced by the reference's render utils (skyjo.py:508-602).
+
+    "traj" cases replay a seeded game (set_seed + stored actions) and render at chosen steps incl. the terminated
+    state; "state" cases render an injected state (a column already collapsed, empty discard pile, hidden cards next
+    to refunded ones) after each action.  The consumer re-creates the state through its own API and compares `==`.
+    """
+    H, O, C = 2, 1, 0
+    out = {}
+    names = []
+
+    def put(name, meta, tables, closed, opened):
+        names.append(name)
+        for k, v in meta.items():
+            out[name + "/" + k] = np.asarray(v)
+        out[name + "/table"] = np.asarray(tables, dtype=np.str_)
+        out[name + "/player_closed"] = np.asarray(closed, dtype=np.str_)
+        out[name + "/player_open"] = np.asarray(opened, dtype=np.str_)
+
+    for N, seed, ind, pen in ((3, 42, True, 2.0), (2, 5, False, 1.0), (4, 9, True, 2.0)):
+        g = SkyjoGame(N, pen, ind)
+        g.set_seed(seed)
+        rng = np.random.default_rng(seed)
+        actions, at, T, Pc, Po = [], [], [], [], []
+        t = 0
+        while True:
+            if t in (0, 1, 2, 17, 40) or g.is_terminated:
+                tb, pc, po = render_strings(g)
+                at.append(t), T.append(tb), Pc.append(pc), Po.append(po)
+            if g.is_terminated:
+                break
+            pid = g.expected_action[0]
+            obs, mask = g.collect_observation(pid)
+            a = int(policy_ra(obs, mask, rng=rng))
+            actions.append(a)
+            g.act(pid, a)
+            t += 1
+        put("traj_N%d_s%d" % (N, seed), dict(kind="traj", cfg=[N, int(ind), seed], penalty=pen,
+                                             actions=np.asarray(actions, dtype=np.int32),
+                                             at=np.asarray(at, dtype=np.int32)), T, Pc, Po)
+
+    cards = [[8, 8, 8, 1, 2, 3, -14, -14, -14, 7, 9, 10], [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]]
+    masked = [[O, O, H, O, H, H, C, C, C, H, O, O], [O, O, H, H, H, H, H, H, H, H, H, H]]
+    for name, ind, draw, disc, player, phase, acts in (
+            ("state_collapsed", True, [4, 5, 6, 12, -2], [7, 0, 0, 0], 0, "draw", [24, 12 + 2, 25, 0]),
+            ("state_empty_discard", False, [4, 5, 6], [7], 1, "draw", [25, 4, 25, 12 + 4])):
+        g = SkyjoGame(2, 2.0, ind)
+        g.players_cards = np.asarray(cards, dtype=np.int8).copy()
+        g.players_masked = np.asarray(masked, dtype=np.int8).copy()
+        g.drawpile = [np.int8(x) for x in draw]
+        g.discard_pile = [np.int8(x) for x in disc]
+        g.hand_card = 15
+        force_turn(g, player, phase)
+        init = snapshot(g)
+        T, Pc, Po = [], [], []
+        for k in range(len(acts) + 1):
+            tb, pc, po = render_strings(g)
+            T.append(tb), Pc.append(pc), Po.append(po)
+            if k < len(acts):
+                g.act(g.expected_action[0], acts[k])
+        meta = dict(kind="state", cfg=[2, int(ind), -1], penalty=2.0, actions=np.asarray(acts, dtype=np.int32),
+                    at=np.arange(len(acts) + 1, dtype=np.int32))
+        meta.update({"init_" + k: v for k, v in init.items()})
+        put(name, meta, T, Pc, Po)
+    out["names"] = np.asarray(names)
+    out["explainer"] = np.asarray([SkyjoGame.render_action_explainer(a) for a in range(26)], dtype=np.str_)
+    out["actions_help"] = np.asarray(SkyjoGame.render_actions(), dtype=np.str_)
+    np.savez_compressed(os.path.join(OUT, "render.npz"), **out)
+    return len(names)
+
+
 def main():
+    if "--render-only" in sys.argv:
+        print("render", gen_render())
+        return
     gen_rng_kat()
     total = 0
     for N in (1, 2, 3, 4):
@@ -453,6 +535,7 @@ def main():
                               mean_reward=0.0, reward_refunded=0.0), 11, "env_N4_ind_s11"))
     print("env", gen_env(dict(skyjo_env.DEFAULT_CONFIG), 3, "env_illegal_draw_s3", illegal_at=4, illegal_action=3))
     print("env", gen_env(dict(skyjo_env.DEFAULT_CONFIG), 3, "env_illegal_place_s3", illegal_at=7, illegal_action=25))
+    print("render", gen_render())
     sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes", sz)
 

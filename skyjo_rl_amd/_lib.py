@@ -9,10 +9,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SKYJO_LIB") or os.path.join(_HERE, "libskyjo_vec.so")  # SKYJO_LIB: diagnostic builds
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_PLAYERS = 12
 ST_OK, ST_ILLEGAL, ST_NOOP_DONE, ST_RESET, ST_WAIT = 0, 1, 2, 3, 4
 RNG_MT19937, RNG_PHILOX = 0, 1
+ACTION_SKIP = -1000  # SKYJO_ACTION_SKIP: leave this game as it is (skyjo_vec_step)
+PROF_KERNELS = ("k_step", "k_scan", "k_deal", "k_publish")
 
 
 class SkyjoNativeError(RuntimeError):
@@ -35,7 +37,8 @@ class Info(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("steps", "episodes", "illegal", "resets", "sum_len", "reshuffles",
                                            "iters", "waits")] + [
-        ("sum_score", C.c_double * MAX_PLAYERS), ("sum_reward", C.c_double * MAX_PLAYERS)]
+        ("sum_score", C.c_double * MAX_PLAYERS), ("sum_reward", C.c_double * MAX_PLAYERS),
+        ("sum_reward_sq", C.c_double * MAX_PLAYERS), ("sum_refunded", C.c_double * MAX_PLAYERS)]
 
 
 class GameState(C.Structure):
@@ -58,6 +61,7 @@ SIGNATURES = {
     "skyjo_vec_destroy": (C.c_int, [VP]),
     "skyjo_vec_get_info": (C.c_int, [VP, C.POINTER(Info)]),
     "skyjo_vec_seed": (C.c_int, [VP, VP, U64, VP]),
+    "skyjo_vec_seed_one": (C.c_int, [VP, I32, U64, VP]),
     "skyjo_vec_reset": (C.c_int, [VP, VP, VP, VP]),
     "skyjo_vec_step": (C.c_int, [VP, VP, VP, VP]),
     "skyjo_vec_rollout": (C.c_int, [VP, I32, U64, VP, VP, VP]),
@@ -76,8 +80,11 @@ SIGNATURES = {
     "skyjo_vec_get_state": (C.c_int, [VP, I32, C.POINTER(GameState), VP]),
     "skyjo_vec_set_state": (C.c_int, [VP, I32, C.POINTER(GameState), VP]),
     "skyjo_vec_seed_raw": (C.c_int, [VP, I32, U32, VP]),
-    "skyjo_vec_profile": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(I64), C.POINTER(C.c_double),
-                                    C.POINTER(I64)]),
+    "skyjo_vec_profile": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(I64)]),
+    "skyjo_vec_snapshot_create": (C.c_int, [VP, C.POINTER(VP), VP]),
+    "skyjo_vec_snapshot_restore": (C.c_int, [VP, VP, VP]),
+    "skyjo_vec_snapshot_bytes": (C.c_int, [VP, C.POINTER(C.c_size_t)]),
+    "skyjo_vec_snapshot_destroy": (C.c_int, [VP]),
     "skyjo_vec_debug_stamps": (C.c_int, [VP, VP]),
     "skyjo_vec_set_option": (C.c_int, [VP, C.c_int, I64]),
     "skyjo_vec_get_option": (C.c_int, [VP, C.c_int, C.POINTER(I64)]),

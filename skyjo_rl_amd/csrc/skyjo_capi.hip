@@ -29,6 +29,21 @@ int fail(int code, const std::string &msg) {
       return fail(SKYJO_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));             \
   } while (0)
 
+// Every entry point that takes a handle runs on the handle's device, whatever the calling thread's current device is
+// (a second thread starts on device 0; torch.cuda.set_device may have switched it), and leaves the caller's current
+// device as it found it.
+struct DevGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DevGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DevGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+#define GUARD(h) DevGuard guard_((h)->cfg.device_id)
+
 constexpr int kMaxRolloutChunk = 128;  // lockstep iterations per k_step launch (the tile stays in LDS for a whole launch)
 // Default number of lockstep iterations between two dealing runs.  A run adds one episode to every bank that is not
 // full, so the interval has to stay below the mean episode length of the policy in use (random admissible policy:
@@ -73,10 +88,22 @@ struct skyjo_vec {
   int32_t *d_actions = nullptr;
   uint8_t *d_records = nullptr;
   uint8_t *d_mask = nullptr;
-  std::vector<void *> allocs;
+  std::vector<std::pair<void *, size_t>> allocs;  // every device array of the handle with its size (snapshots copy them all)
   // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
   bool profile = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_step, ev_deal;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[SKYJO_PROF_KERNELS];  // k_step, k_scan, k_deal, k_publish
+};
+
+struct skyjo_vec_snapshot {
+  const skyjo_vec *owner = nullptr;
+  int device_id = 0;
+  void *blob = nullptr;
+  size_t bytes = 0;
+  // host side of the engine's state
+  int pending_iters = 0, deal_every_iters = 0, calm_runs = 0, list_sel = 0;
+  bool auto_interval = true;
+  uint32_t health_seen = 0, deal_tag = 0, health[2] = {0, 0};
+  uint64_t iter = 0, iters_total = 0;
 };
 
 namespace {
@@ -86,19 +113,19 @@ int dalloc(skyjo_vec *h, T **out, size_t count, bool zero = true) {
   void *p = nullptr;
   HIPCHK(hipMalloc(&p, count * sizeof(T)));
   if (zero) HIPCHK(hipMemset(p, 0, count * sizeof(T)));
-  h->allocs.push_back(p);
+  h->allocs.emplace_back(p, count * sizeof(T));
   *out = (T *)p;
   return SKYJO_OK;
 }
 
 // Profiling: the kernel's own begin / end timestamps (the dispatch packet's completion signal, the same
 // source rocprofv3's kernel trace reads) are attached to a pair of events by hipExtLaunchKernelGGL.
-int prof_events(skyjo_vec *h, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, hipEvent_t *a, hipEvent_t *b) {
+int prof_events(skyjo_vec *h, int kernel, hipEvent_t *a, hipEvent_t *b) {
   *a = *b = nullptr;
   if (!h->profile) return SKYJO_OK;
   HIPCHK(hipEventCreate(a));
   HIPCHK(hipEventCreate(b));
-  v.emplace_back(*a, *b);
+  h->ev[kernel].emplace_back(*a, *b);
   return SKYJO_OK;
 }
 
@@ -106,7 +133,10 @@ int prof_events(skyjo_vec *h, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v,
 int publish_deals(skyjo_vec *h, hipStream_t s) {
   if (!h->deal_inflight) return SKYJO_OK;
   if (h->overlap) HIPCHK(hipStreamWaitEvent(s, h->ev_dealt, 0));
-  hipLaunchKernelGGL(k_publish, dim3(64), dim3(256), 0, s, h->P, h->list_sel);
+  hipEvent_t e0, e1;
+  int rc = prof_events(h, 3, &e0, &e1);
+  if (rc) return rc;
+  hipExtLaunchKernelGGL(k_publish, dim3(64), dim3(256), 0, s, e0, e1, 0, h->P, h->list_sel);
   HIPCHK(hipGetLastError());
   h->deal_inflight = false;
   return SKYJO_OK;
@@ -143,7 +173,10 @@ int start_deals(skyjo_vec *h, hipStream_t s) {
   if (h->deal_tag == 0) h->deal_tag = 1;
   h->P.deal_tag = h->deal_tag;
   // (the list's counter was cleared by the previous run's publish step)
-  hipLaunchKernelGGL(k_scan, dim3((h->P.B + SK_SCAN_BLOCK - 1) / SK_SCAN_BLOCK), dim3(SK_SCAN_BLOCK), 0, s, h->P, h->list_sel);
+  hipEvent_t e0, e1;
+  if ((rc = prof_events(h, 1, &e0, &e1))) return rc;
+  hipExtLaunchKernelGGL(k_scan, dim3((h->P.B + SK_SCAN_BLOCK - 1) / SK_SCAN_BLOCK), dim3(SK_SCAN_BLOCK), 0, s, e0, e1, 0, h->P,
+                        h->list_sel);
   HIPCHK(hipGetLastError());
   hipStream_t ds = s;
   if (h->overlap) {
@@ -151,8 +184,7 @@ int start_deals(skyjo_vec *h, hipStream_t s) {
     HIPCHK(hipStreamWaitEvent(h->deal_stream, h->ev_scan, 0));
     ds = h->deal_stream;
   }
-  hipEvent_t e0, e1;
-  if ((rc = prof_events(h, h->ev_deal, &e0, &e1))) return rc;
+  if ((rc = prof_events(h, 2, &e0, &e1))) return rc;
   // fixed player counts deal from a 150-word strip per lane (one card per dword); the generic kernel needs the tile + ring
   const int inl = h->overlap ? 0 : 1;  // in line: k_deal publishes its own episodes, no k_publish launch
   const uint32_t lds_compact = SK_NCARDS * 256, lds_generic = (uint32_t)(h->lds_tile + 16384);
@@ -175,7 +207,7 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
   const bool ind = h->P.L.indirect != 0;
   int rc;
   hipEvent_t e0, e1;
-  if ((rc = prof_events(h, h->ev_step, &e0, &e1))) return rc;
+  if ((rc = prof_events(h, 0, &e0, &e1))) return rc;
 #define LAUNCH3(I, Pol, NP)                                                                                       \
   hipExtLaunchKernelGGL((k_step<I, Pol, NP>), grid, block, (uint32_t)h->lds_bytes, s, e0, e1, 0, h->P, actions,   \
                         rec, act_out, iters, policy_seed, h->iter)
@@ -232,7 +264,7 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   HIPCHK(hipGetDeviceProperties(&prop, cfg->device_id));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("SKYJO_ALLOW_ANY_GPU"))
     return fail(SKYJO_E_NOGPU, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950");
-  HIPCHK(hipSetDevice(cfg->device_id));
+  DevGuard guard_(cfg->device_id);  // (the caller's current device is restored on return)
 
   skyjo_vec *h = new (std::nothrow) skyjo_vec();
   if (!h) return fail(SKYJO_E_INVALID, "out of host memory");
@@ -248,9 +280,14 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   P.game_id0 = cfg->game_id0;
   h->G = (size_t)P.tiles * SK_TILE;
   h->lds_tile = (size_t)P.L.chunks * 1024;
-  // tile + 16-word RNG scratch + float64 sums + one iteration's records (64 B each, or rec_bytes (+16) for the direct observation)
-  h->lds_bytes = h->lds_tile + 4096 + 2 * (size_t)cfg->num_players * 512 + (size_t)SK_TILE * (P.L.indirect ? 64 : P.L.rec_bytes + 16);
+  // tile + one iteration's records (64 B each, or rec_bytes + 16 for the direct observation; the rare paths' RNG scratch
+  // aliases this area) + the wavefront's per-seat float64 statistics
+  h->lds_bytes = h->lds_tile + (size_t)SK_TILE * (P.L.indirect ? 64 : P.L.rec_bytes + 16) + (size_t)SK_ACC_KINDS * cfg->num_players * 8;
   const size_t rec16 = (size_t)P.tiles * P.L.chunks * SK_TILE;
+  if ((uint64_t)SK_BANK * rec16 * 16 >= (1ull << 32)) {  // (LDS-DMA addresses the bank with 32-bit offsets)
+    delete h;
+    return fail(SKYJO_E_INVALID, "num_envs too large for one handle");
+  }
   int rc = SKYJO_OK;
   const size_t N = (size_t)cfg->num_players;
   if ((rc = dalloc(h, &P.state, rec16)) || (rc = dalloc(h, &P.spare, SK_BANK * rec16)) ||
@@ -261,7 +298,7 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
       (rc = dalloc(h, &P.mt_idx, (1 + SK_BANK) * h->G)) || (rc = dalloc(h, &P.seeds, h->G)) ||
       (rc = dalloc(h, &P.deals_consumed, h->G)) || (rc = dalloc(h, &P.rewards, h->G * N)) ||
       (rc = dalloc(h, &P.scores, h->G * N)) || (rc = dalloc(h, &P.done, h->G)) ||
-      (rc = dalloc(h, &P.acc_tile, (size_t)P.tiles * 2 * SKYJO_MAX_PLAYERS)) ||
+      (rc = dalloc(h, &P.acc_tile, (size_t)P.tiles * SK_ACC_KINDS * SKYJO_MAX_PLAYERS)) || (rc = dalloc(h, &P.dev_error, 1)) ||
       (rc = dalloc(h, &P.counters, 1)) || (rc = dalloc(h, &P.tile_counters, (size_t)P.tiles * 8)) || (rc = dalloc(h, &P.stamps, (size_t)P.tiles * 16))) {
     skyjo_vec_destroy(h);
     return rc;
@@ -299,11 +336,14 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
 
 int skyjo_vec_destroy(skyjo_vec *h) {
   if (!h) return SKYJO_OK;
+  GUARD(h);
   (void)hipDeviceSynchronize();
   if (h->deal_stream) (void)hipStreamDestroy(h->deal_stream);
   if (h->ev_scan) (void)hipEventDestroy(h->ev_scan);
   if (h->ev_dealt) (void)hipEventDestroy(h->ev_dealt);
-  for (void *p : h->allocs) (void)hipFree(p);
+  for (auto &p : h->allocs) (void)hipFree(p.first);
+  for (auto &v : h->ev)
+    for (auto &e : v) (void)hipEventDestroy(e.first), (void)hipEventDestroy(e.second);
   if (h->health_host) (void)hipHostFree(h->health_host);
   delete h;
   return SKYJO_OK;
@@ -320,7 +360,7 @@ int skyjo_vec_get_info(const skyjo_vec *h, skyjo_vec_info *out) {
 int skyjo_vec_seed(skyjo_vec *h, const uint64_t *seeds_host, uint64_t base_seed, void *stream) {
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
   hipStream_t s = (hipStream_t)stream;
-  HIPCHK(hipSetDevice(h->cfg.device_id));
+  GUARD(h);
   uint64_t *d_seeds = nullptr;
   if (seeds_host) {
     HIPCHK(hipMalloc((void **)&d_seeds, sizeof(uint64_t) * (size_t)h->P.B));
@@ -348,8 +388,107 @@ int skyjo_vec_seed(skyjo_vec *h, const uint64_t *seeds_host, uint64_t base_seed,
   return skyjo_vec_reset_counters(h, stream);
 }
 
+static int ensure_scratch(skyjo_vec *h);
+
+int skyjo_vec_seed_one(skyjo_vec *h, int32_t game, uint64_t value, void *stream) {
+  if (!h || game < 0 || game >= h->P.B) return fail(SKYJO_E_INVALID, "bad argument");
+  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  GUARD(h);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = ensure_scratch(h)) || (rc = publish_deals(h, s))) return rc;  // nobody else may be using the stream that is re-seeded
+  uint64_t *d_seed = (uint64_t *)h->d_actions;                               // (8 bytes of the host-style scratch)
+  HIPCHK(hipMemcpyAsync(d_seed, &value, sizeof(value), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));  // (`value` lives on this stack frame)
+  hipLaunchKernelGGL(k_seed, dim3(1), dim3(64), 0, s, h->P, (const uint64_t *)d_seed, (uint64_t)0, (int)game, 1);
+  HIPCHK(hipGetLastError());
+  if ((rc = start_deals(h, s)) || (rc = publish_deals(h, s))) return rc;  // deal #0 of the new stream ...
+  HIPCHK(hipMemsetAsync(h->d_mask, 0, h->G, s));
+  const uint8_t one = 1;
+  HIPCHK(hipMemcpyAsync(h->d_mask + game, &one, 1, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if ((rc = skyjo_vec_reset(h, h->d_mask, nullptr, stream))) return rc;    // ... becomes the live game
+  for (int k = 1; k < SK_BANK; k++)
+    if ((rc = start_deals(h, s)) || (rc = publish_deals(h, s))) return rc;
+  return SKYJO_OK;
+}
+
+int skyjo_vec_snapshot_create(skyjo_vec *h, skyjo_vec_snapshot **out, void *stream) {
+  if (!h || !out) return fail(SKYJO_E_INVALID, "null argument");
+  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  GUARD(h);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = publish_deals(h, s))) return rc;  // no deal in flight: the arrays below are the whole truth
+  HIPCHK(hipDeviceSynchronize());
+  skyjo_vec_snapshot *sn = new (std::nothrow) skyjo_vec_snapshot();
+  if (!sn) return fail(SKYJO_E_INVALID, "out of host memory");
+  sn->owner = h, sn->device_id = h->cfg.device_id;
+  for (auto &a : h->allocs) sn->bytes += (a.second + 255) & ~(size_t)255;
+  if (hipMalloc(&sn->blob, sn->bytes) != hipSuccess) {
+    delete sn;
+    return fail(SKYJO_E_DEVICE, "hipMalloc failed for the snapshot");
+  }
+  size_t off = 0;
+  for (auto &a : h->allocs) {
+    hipError_t e = hipMemcpyAsync((uint8_t *)sn->blob + off, a.first, a.second, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) {
+      (void)hipFree(sn->blob);
+      delete sn;
+      return fail(SKYJO_E_DEVICE, std::string("snapshot copy: ") + hipGetErrorString(e));
+    }
+    off += (a.second + 255) & ~(size_t)255;
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  sn->pending_iters = h->pending_iters, sn->deal_every_iters = h->deal_every_iters, sn->calm_runs = h->calm_runs;
+  sn->list_sel = h->list_sel, sn->auto_interval = h->auto_interval, sn->health_seen = h->health_seen;
+  sn->deal_tag = h->deal_tag, sn->iter = h->iter, sn->iters_total = h->iters_total;
+  sn->health[0] = h->health_host[0], sn->health[1] = h->health_host[1];
+  *out = sn;
+  return SKYJO_OK;
+}
+
+int skyjo_vec_snapshot_restore(skyjo_vec *h, const skyjo_vec_snapshot *sn, void *stream) {
+  if (!h || !sn) return fail(SKYJO_E_INVALID, "null argument");
+  if (sn->owner != h) return fail(SKYJO_E_INVALID, "the snapshot was taken from another handle");
+  GUARD(h);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = publish_deals(h, s))) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  size_t off = 0, n = 0;
+  for (auto &a : h->allocs) {  // (arrays allocated after the snapshot - the host-style scratch - are not part of it)
+    const size_t padded = (a.second + 255) & ~(size_t)255;
+    if (off + padded > sn->bytes) break;
+    HIPCHK(hipMemcpyAsync(a.first, (const uint8_t *)sn->blob + off, a.second, hipMemcpyDeviceToDevice, s));
+    off += padded, n++;
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  h->pending_iters = sn->pending_iters, h->deal_every_iters = sn->deal_every_iters, h->calm_runs = sn->calm_runs;
+  h->list_sel = sn->list_sel, h->auto_interval = sn->auto_interval, h->health_seen = sn->health_seen;
+  h->deal_tag = sn->deal_tag, h->P.deal_tag = sn->deal_tag, h->iter = sn->iter, h->iters_total = sn->iters_total;
+  h->health_host[0] = sn->health[0], h->health_host[1] = sn->health[1];
+  h->deal_inflight = false;
+  return SKYJO_OK;
+}
+
+int skyjo_vec_snapshot_bytes(const skyjo_vec_snapshot *sn, size_t *bytes_out) {
+  if (!sn || !bytes_out) return fail(SKYJO_E_INVALID, "null argument");
+  *bytes_out = sn->bytes;
+  return SKYJO_OK;
+}
+
+int skyjo_vec_snapshot_destroy(skyjo_vec_snapshot *sn) {
+  if (!sn) return SKYJO_OK;
+  DevGuard guard_(sn->device_id);
+  (void)hipFree(sn->blob);
+  delete sn;
+  return SKYJO_OK;
+}
+
 int skyjo_vec_reset(skyjo_vec *h, const uint8_t *mask, void *records_out, void *stream) {
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
+  GUARD(h);
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   hipStream_t s = (hipStream_t)stream;
   int rc;
@@ -366,6 +505,7 @@ int skyjo_vec_reset(skyjo_vec *h, const uint8_t *mask, void *records_out, void *
 
 int skyjo_vec_step(skyjo_vec *h, const int32_t *actions, void *records_out, void *stream) {
   if (!h || !actions) return fail(SKYJO_E_INVALID, "null argument");
+  GUARD(h);
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   hipStream_t s = (hipStream_t)stream;
   int rc = launch_step(h, s, false, actions, (uint8_t *)records_out, nullptr, 1, 0);
@@ -377,6 +517,7 @@ int skyjo_vec_step(skyjo_vec *h, const int32_t *actions, void *records_out, void
 int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *records_out, int32_t *actions_out,
                       void *stream) {
   if (!h || iters < 0) return fail(SKYJO_E_INVALID, "bad argument");
+  GUARD(h);
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   hipStream_t s = (hipStream_t)stream;
   uint8_t *rec = (uint8_t *)records_out;
@@ -395,6 +536,7 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
 
 int skyjo_vec_observe(skyjo_vec *h, const int32_t *players, void *records_out, void *stream) {
   if (!h || !records_out) return fail(SKYJO_E_INVALID, "null argument");
+  GUARD(h);
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   dim3 grid(h->P.tiles), block(SK_TILE);
   hipStream_t s = (hipStream_t)stream;
@@ -409,6 +551,7 @@ int skyjo_vec_observe(skyjo_vec *h, const int32_t *players, void *records_out, v
 int skyjo_vec_unpack(skyjo_vec *h, const void *records, int64_t n, int8_t *obs, int8_t *mask, uint8_t *agent,
                      uint8_t *phase, uint8_t *done, uint8_t *status, void *stream) {
   if (!h || !records || n < 0) return fail(SKYJO_E_INVALID, "bad argument");
+  GUARD(h);
   if (n == 0) return SKYJO_OK;
   long long total = n * (long long)(h->P.L.D + 26);
   int blocks = (int)((total + 255) / 256);
@@ -427,6 +570,7 @@ int skyjo_vec_sample_actions(skyjo_vec *h, const void *records, const float *log
                              uint64_t ticket, int32_t no_masking, int32_t *actions_out, float *logp_out,
                              float *uniform_out, void *stream) {
   if (!h || !records || !logits || !actions_out || n < 0) return fail(SKYJO_E_INVALID, "null argument");
+  GUARD(h);
   if (n == 0) return SKYJO_OK;
   const int64_t blocks = (n + SK_SAMPLE_BLOCK - 1) / SK_SAMPLE_BLOCK;
   hipLaunchKernelGGL(k_sample, dim3((unsigned)blocks), dim3(SK_SAMPLE_BLOCK), 0, (hipStream_t)stream, h->P.L,
@@ -441,7 +585,9 @@ int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, co
   if (!out || !w1 || !b1 || !w2 || !b2 || !w3 || !b3) return fail(SKYJO_E_INVALID, "null argument");
   if (obs_dim < 1 || obs_dim > SKP_IN - 1 || out_dim < 1 || out_dim > SKP_OUT)
     return fail(SKYJO_E_INVALID, "skyjo_vec_mlp: obs_dim must be 1..31 and out_dim 1..32");
-  HIPCHK(hipSetDevice(device_id));
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return fail(SKYJO_E_INVALID, "device_id out of range");
+  DevGuard guard_(device_id);
   auto bf16 = [](float f) {  // round to nearest even
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -501,6 +647,7 @@ int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, co
 
 int skyjo_vec_mlp_destroy(skyjo_vec_mlp *m) {
   if (!m) return SKYJO_OK;
+  DevGuard guard_(m->device_id);
   (void)hipFree(m->blob);
   delete m;
   return SKYJO_OK;
@@ -511,6 +658,7 @@ int skyjo_vec_mlp_forward(const skyjo_vec_mlp *m, const void *records, int32_t r
   if (!m || !records || !out || n < 0 || record_bytes < 32 || (record_bytes & 15))
     return fail(SKYJO_E_INVALID, "skyjo_vec_mlp_forward: bad argument");
   if (n == 0) return SKYJO_OK;
+  DevGuard guard_(m->device_id);
   SkMlpDraw nodraw{};
   hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT - 1) / (32 * SKP_GT))), dim3(64), 0, (hipStream_t)stream, m->net,
                      (const uint8_t *)records, (int)record_bytes, m->obs_dim, (long long)n, out, nodraw);
@@ -521,6 +669,7 @@ int skyjo_vec_mlp_forward(const skyjo_vec_mlp *m, const void *records, int32_t r
 int skyjo_vec_mlp_act(skyjo_vec *h, const skyjo_vec_mlp *m, const void *records, int64_t n, uint64_t seed, uint64_t ticket,
                       int32_t no_masking, int32_t *actions_out, float *logp_out, float *logits_out, void *stream) {
   if (!h || !m || !records || !actions_out || n < 0) return fail(SKYJO_E_INVALID, "skyjo_vec_mlp_act: bad argument");
+  GUARD(h);
   if (m->net.out_dim != SKYJO_NUM_ACTIONS) return fail(SKYJO_E_INVALID, "skyjo_vec_mlp_act needs a net with 26 outputs");
   if (n == 0) return SKYJO_OK;
   SkMlpDraw d{};
@@ -534,20 +683,27 @@ int skyjo_vec_mlp_act(skyjo_vec *h, const skyjo_vec_mlp *m, const void *records,
 
 int skyjo_vec_get_counters(skyjo_vec *h, skyjo_vec_counters *out, void *stream) {
   if (!h || !out) return fail(SKYJO_E_INVALID, "null argument");
+  GUARD(h);
   static_assert(sizeof(SkCounters) == sizeof(skyjo_vec_counters), "counter structs must match");
   hipStream_t s = (hipStream_t)stream;
   HIPCHK(hipMemsetAsync(h->P.counters, 0, sizeof(SkCounters), s));
   hipLaunchKernelGGL(k_reduce_stats, dim3(64), dim3(256), 0, s, h->P);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, h->P.counters, sizeof(SkCounters), hipMemcpyDeviceToHost, s));
+  uint32_t err = 0;
+  HIPCHK(hipMemcpyAsync(&err, h->P.dev_error, sizeof(err), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   out->iters = h->iters_total;
+  if (err & SK_ERR_DEAL_TIMEOUT)
+    return fail(SKYJO_E_DEVICE, "a step kernel gave up waiting for the dealing kernel that should run beside it (SKYJO_OPT_OVERLAP): "
+                                "results since then are void; switch the option off or re-seed");
   return SKYJO_OK;
 }
 
 int skyjo_vec_reset_counters(skyjo_vec *h, void *stream) {
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
-  const size_t n = (size_t)h->P.tiles * 2 * SKYJO_MAX_PLAYERS * sizeof(double);
+  GUARD(h);
+  const size_t n = (size_t)h->P.tiles * SK_ACC_KINDS * SKYJO_MAX_PLAYERS * sizeof(double);
   h->iters_total = 0;
   HIPCHK(hipMemsetAsync(h->P.counters, 0, sizeof(SkCounters), (hipStream_t)stream));
   HIPCHK(hipMemsetAsync(h->P.tile_counters, 0, (size_t)h->P.tiles * 8 * sizeof(unsigned long long), (hipStream_t)stream));
@@ -557,6 +713,7 @@ int skyjo_vec_reset_counters(skyjo_vec *h, void *stream) {
 
 int skyjo_vec_get_state(skyjo_vec *h, int32_t game, skyjo_game_state *o, void *stream) {
   if (!h || !o || game < 0 || game >= h->P.B) return fail(SKYJO_E_INVALID, "bad argument");
+  GUARD(h);
   hipStream_t s = (hipStream_t)stream;
   const SkLayout &L = h->P.L;
   std::vector<uint8_t> r;
@@ -565,7 +722,7 @@ int skyjo_vec_get_state(skyjo_vec *h, int32_t game, skyjo_game_state *o, void *s
   memset(o, 0, sizeof(*o));
   for (int p = 0; p < L.N; p++)
     for (int k = 0; k < 12; k++) {
-      int8_t c = (int8_t)r[L.off_cards + 12 * p + k], v = (int8_t)r[L.off_vis + 12 * p + k];
+      int8_t c = (int8_t)r[sk_pb(L, p) + PB_CARDS + k], v = (int8_t)r[sk_pb(L, p) + PB_VIS + k];
       o->players_cards[p][k] = c;
       o->players_masked[p][k] = v == SKYJO_HAND_NONE ? 2 : (v == SKYJO_REFUNDED ? 0 : 1);
     }
@@ -582,9 +739,9 @@ int skyjo_vec_get_state(skyjo_vec *h, int32_t game, skyjo_game_state *o, void *s
   memcpy(&o->episode, &r[H_EPISODE], 4);
   o->reshuffles = r[H_RESH];
   for (int p = 0; p < L.N; p++) {
-    o->num_refunded[p] = r[L.off_refunded + p];
+    o->num_refunded[p] = r[sk_pb(L, p) + PB_REFUNDED];
     uint16_t pl;
-    memcpy(&pl, &r[L.off_placed + 2 * p], 2);
+    memcpy(&pl, &r[sk_pb(L, p) + PB_PLACED], 2);
     o->num_placed[p] = pl;
   }
   if (o->done) {
@@ -599,6 +756,7 @@ int skyjo_vec_get_state(skyjo_vec *h, int32_t game, skyjo_game_state *o, void *s
 
 int skyjo_vec_set_state(skyjo_vec *h, int32_t game, const skyjo_game_state *in, void *stream) {
   if (!h || !in || game < 0 || game >= h->P.B) return fail(SKYJO_E_INVALID, "bad argument");
+  GUARD(h);
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   const SkLayout &L = h->P.L;
   if (in->n_draw < 0 || in->n_disc < 0 || in->n_draw + in->n_disc > SK_NCARDS)
@@ -615,8 +773,8 @@ int skyjo_vec_set_state(skyjo_vec *h, int32_t game, const skyjo_game_state *in, 
       if (c < -2 && !(m == 0 && c == SKYJO_REFUNDED)) return fail(SKYJO_E_INVALID, "card value out of range");
       if (c > 12) return fail(SKYJO_E_INVALID, "card value out of range");
       int8_t v = m == 2 ? (int8_t)SKYJO_HAND_NONE : (m == 0 ? (int8_t)SKYJO_REFUNDED : c);
-      r[L.off_cards + 12 * p + k] = (uint8_t)(m == 0 ? (int8_t)SKYJO_REFUNDED : c);
-      r[L.off_vis + 12 * p + k] = (uint8_t)v;
+      r[sk_pb(L, p) + PB_CARDS + k] = (uint8_t)(m == 0 ? (int8_t)SKYJO_REFUNDED : c);
+      r[sk_pb(L, p) + PB_VIS + k] = (uint8_t)v;
       if (m == 1) {
         sum += c;
         if (!L.indirect) r[H_HIST + 2 + c]++;
@@ -624,11 +782,11 @@ int skyjo_vec_set_state(skyjo_vec *h, int32_t game, const skyjo_game_state *in, 
       if (m == 2) hid++;
     }
     int16_t s16 = (int16_t)sum;
-    memcpy(&r[L.off_sums + 2 * p], &s16, 2);
-    r[L.off_hidden + p] = (uint8_t)hid;
-    r[L.off_refunded + p] = (uint8_t)in->num_refunded[p];
+    memcpy(&r[sk_pb(L, p) + PB_SUM], &s16, 2);
+    r[sk_pb(L, p) + PB_HIDDEN] = (uint8_t)hid;
+    r[sk_pb(L, p) + PB_REFUNDED] = (uint8_t)in->num_refunded[p];
     uint16_t pl = (uint16_t)in->num_placed[p];
-    memcpy(&r[L.off_placed + 2 * p], &pl, 2);
+    memcpy(&r[sk_pb(L, p) + PB_PLACED], &pl, 2);
     ms = sum < ms ? sum : ms, mh = hid < mh ? hid : mh;
   }
   for (int k = 0; k < in->n_draw; k++) r[L.off_pile + k] = (uint8_t)in->drawpile[k];
@@ -666,6 +824,7 @@ int skyjo_vec_set_state(skyjo_vec *h, int32_t game, const skyjo_game_state *in, 
 
 int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream) {
   if (!h || game < 0 || game >= h->P.B) return fail(SKYJO_E_INVALID, "bad argument");
+  GUARD(h);
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   if (h->P.rng_mode != SKYJO_RNG_MT19937) return fail(SKYJO_E_STATE, "seed_raw needs the MT19937 mode");
   hipStream_t s = (hipStream_t)stream;
@@ -677,32 +836,30 @@ int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream)
   return publish_deals(h, s);
 }
 
-int skyjo_vec_profile(skyjo_vec *h, int enable, double *step_ms, int64_t *step_launches, double *deal_ms,
-                      int64_t *deal_launches) {
+int skyjo_vec_profile(skyjo_vec *h, int enable, double ms_out[SKYJO_PROF_KERNELS], int64_t launches_out[SKYJO_PROF_KERNELS]) {
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
+  GUARD(h);
   HIPCHK(hipDeviceSynchronize());
-  double tot[2] = {0, 0};
-  int64_t cnt[2] = {0, 0};
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> *v[2] = {&h->ev_step, &h->ev_deal};
-  for (int k = 0; k < 2; k++) {
-    for (auto &p : *v[k]) {
+  for (int k = 0; k < SKYJO_PROF_KERNELS; k++) {
+    double tot = 0;
+    int64_t cnt = 0;
+    for (auto &p : h->ev[k]) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) tot[k] += ms, cnt[k]++;
+      if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) tot += ms, cnt++;
       (void)hipEventDestroy(p.first);
       (void)hipEventDestroy(p.second);
     }
-    v[k]->clear();
+    h->ev[k].clear();
+    if (ms_out) ms_out[k] = tot;
+    if (launches_out) launches_out[k] = cnt;
   }
-  if (step_ms) *step_ms = tot[0];
-  if (step_launches) *step_launches = cnt[0];
-  if (deal_ms) *deal_ms = tot[1];
-  if (deal_launches) *deal_launches = cnt[1];
   h->profile = enable != 0;
   return SKYJO_OK;
 }
 
 int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host) {
   if (!h || !out16_host) return fail(SKYJO_E_INVALID, "null argument");
+  GUARD(h);
   const size_t half = (size_t)h->P.tiles * 8;
   std::vector<unsigned long long> t(2 * half);
   HIPCHK(hipMemcpy(t.data(), h->P.stamps, t.size() * 8, hipMemcpyDeviceToHost));
@@ -723,6 +880,7 @@ int skyjo_vec_get_option(const skyjo_vec *h, int option, int64_t *value_out) {
 
 int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
+  GUARD(h);
   switch (option) {
     case SKYJO_OPT_DEAL_INTERVAL:
       if (value < 1 || value > 1024) return fail(SKYJO_E_INVALID, "deal interval must be in 1..1024");
@@ -751,6 +909,7 @@ static int ensure_scratch(skyjo_vec *h) {
 
 int skyjo_vec_step_host(skyjo_vec *h, const int32_t *actions_host, void *records_out_host) {
   if (!h || !actions_host) return fail(SKYJO_E_INVALID, "null argument");
+  GUARD(h);
   int rc = ensure_scratch(h);
   if (rc) return rc;
   HIPCHK(hipMemcpy(h->d_actions, actions_host, sizeof(int32_t) * (size_t)h->P.B, hipMemcpyHostToDevice));
@@ -764,6 +923,7 @@ int skyjo_vec_step_host(skyjo_vec *h, const int32_t *actions_host, void *records
 
 int skyjo_vec_observe_host(skyjo_vec *h, const int32_t *players_host, void *records_out_host) {
   if (!h || !records_out_host) return fail(SKYJO_E_INVALID, "null argument");
+  GUARD(h);
   int rc = ensure_scratch(h);
   if (rc) return rc;
   if (players_host)
@@ -775,6 +935,7 @@ int skyjo_vec_observe_host(skyjo_vec *h, const int32_t *players_host, void *reco
 
 int skyjo_vec_reset_host(skyjo_vec *h, const uint8_t *mask_host, void *records_out_host) {
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
+  GUARD(h);
   int rc = ensure_scratch(h);
   if (rc) return rc;
   if (mask_host) HIPCHK(hipMemcpy(h->d_mask, mask_host, (size_t)h->P.B, hipMemcpyHostToDevice));
@@ -788,6 +949,7 @@ int skyjo_vec_reset_host(skyjo_vec *h, const uint8_t *mask_host, void *records_o
 
 int skyjo_vec_get_rewards_host(skyjo_vec *h, double *rewards_out, double *scores_out, uint8_t *done_out) {
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
+  GUARD(h);
   const size_t n = (size_t)h->P.B * h->P.L.N;
   if (rewards_out) HIPCHK(hipMemcpy(rewards_out, h->P.rewards, n * sizeof(double), hipMemcpyDeviceToHost));
   if (scores_out) HIPCHK(hipMemcpy(scores_out, h->P.scores, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -797,7 +959,7 @@ int skyjo_vec_get_rewards_host(skyjo_vec *h, double *rewards_out, double *scores
 
 int skyjo_dev_malloc(int device_id, size_t bytes, void **out) {
   if (!out) return fail(SKYJO_E_INVALID, "null argument");
-  HIPCHK(hipSetDevice(device_id));
+  DevGuard guard_(device_id);
   HIPCHK(hipMalloc(out, bytes ? bytes : 1));
   return SKYJO_OK;
 }

@@ -20,7 +20,11 @@ struct SkCounters {
   unsigned long long steps, episodes, illegal, resets, sum_len, reshuffles, iters, waits;
   double sum_score[SKYJO_MAX_PLAYERS];
   double sum_reward[SKYJO_MAX_PLAYERS];
+  double sum_reward_sq[SKYJO_MAX_PLAYERS];
+  double sum_refunded[SKYJO_MAX_PLAYERS];
 };
+#define SK_ERR_DEAL_TIMEOUT 1u  // bits of SkParams.dev_error
+#define SK_ACC_KINDS 4  // per-seat float64 statistics kept per tile: score, reward, reward^2, refunded
 
 // Pre-dealt episodes per game.  Deeper banks ride out longer gaps between dealing runs, but their records share the
 // 256 MB memory-side cache with the 164 MB of generator state the dealing kernel works on: at 65 536 three-player
@@ -55,7 +59,8 @@ struct SkParams {
   double *rewards;          // [tiles*64][N]
   double *scores;           // [tiles*64][N]
   uint8_t *done;            // [tiles*64]
-  double *acc_tile;         // [tiles][2][12] per-wavefront sums of final scores / rewards per seat
+  double *acc_tile;         // [tiles][SK_ACC_KINDS][12] per-wavefront sums per seat: final score, reward, reward^2, num_refunded
+  uint32_t *dev_error;      // [1] sticky: set by a kernel that had to give up (SK_ERR_*), reported by skyjo_vec_get_counters
   SkCounters *counters;
   unsigned long long *tile_counters;  // [tiles][8] per-wavefront event counts (no same-address atomics)
   unsigned long long *stamps;         // [tiles][8] section cycle sums, written only by -DSK_STAMPS diagnostic builds
@@ -66,14 +71,16 @@ struct LaneCounters {
 };
 
 // ------------------------------------------------------------------------------------------
-// LDS addressing: lp = tile base + lane * 4 ; byte b of this lane's record lives at lp[LIDX(b)]
+// LDS addressing: lp = tile base + lane * 16 ; byte b of this lane's record lives at lp[LIDX(b)]
+// (chunk-major, skyjo_layout.h); LQ(c) is the lane's whole 16-byte chunk c (one ds_read_b128 / ds_write_b128).
 // ------------------------------------------------------------------------------------------
-#define LIDX(b) ((((b) >> 2) << 8) | ((b) & 3))
+#define LIDX(b) ((((b) >> 4) << 10) | ((b) & 15))
 #define LB(b) (lp[LIDX(b)])
 #define LI(b) ((int)(int8_t)lp[LIDX(b)])
-#define LW(w) (*(uint32_t *)(lp + ((w) << 8)))
+#define LW(w) (*(uint32_t *)(lp + LIDX(4 * (w))))
 #define LH(b) (*(uint16_t *)(lp + LIDX(b)))
 #define LSH(b) (*(int16_t *)(lp + LIDX(b)))
+#define LQ(c) (*(uint4 *)(lp + ((c) << 10)))
 
 // Groups of 6 chunks: all global loads of a group are issued before the first LDS write, so a tile
 // costs ceil(chunks / 6) memory round trips instead of one per chunk (the trip count is a run-time
@@ -88,10 +95,7 @@ __device__ __forceinline__ void tile_load(const SkParams &P, const uint4 *src, i
       if (c + k < n) v[k] = s[(size_t)(c + k) * SK_TILE];
 #pragma unroll
     for (int k = 0; k < 6; k++)
-      if (c + k < n) {
-        const int w = 4 * (c + k);
-        LW(w + 0) = v[k].x, LW(w + 1) = v[k].y, LW(w + 2) = v[k].z, LW(w + 3) = v[k].w;
-      }
+      if (c + k < n) LQ(c + k) = v[k];
   }
 }
 
@@ -102,10 +106,7 @@ __device__ __forceinline__ void tile_store(const SkParams &P, uint4 *dst, int ti
     uint4 v[6];
 #pragma unroll
     for (int k = 0; k < 6; k++)
-      if (c + k < n) {
-        const int w = 4 * (c + k);
-        v[k].x = LW(w + 0), v[k].y = LW(w + 1), v[k].z = LW(w + 2), v[k].w = LW(w + 3);
-      }
+      if (c + k < n) v[k] = LQ(c + k);
 #pragma unroll
     for (int k = 0; k < 6; k++)
       if (c + k < n) d[(size_t)(c + k) * SK_TILE] = v[k];
@@ -115,49 +116,61 @@ __device__ __forceinline__ void tile_store(const SkParams &P, uint4 *dst, int ti
 // k_step's own tile I/O: non-temporal.  The live tiles are read at the start and written at the end of a launch of
 // ~140 us; kept out of the memory-side cache they leave it to the generator state and the bank - with them inside,
 // about every third process ran its dealing kernel at 95 instead of 80 us (where the driver had put the pages), with
-// them outside none of 8 did, at +2 % for k_step.  All chunks of the load are requested in one go (one memory round trip).
+// them outside none of 8 did, at +2 % for k_step.
 typedef uint32_t sk_u32x4_nt __attribute__((ext_vector_type(4)));
-template <int CH>
-__device__ __forceinline__ void tile_load_nt(const SkParams &P, const uint4 *src, int tile, int lane, uint8_t *lp) {
-  const sk_u32x4_nt *s = (const sk_u32x4_nt *)(src + (size_t)tile * P.L.chunks * SK_TILE + lane);
-  if (CH > 0) {
-    sk_u32x4_nt v[CH > 0 ? CH : 1];
-#pragma unroll
-    for (int k = 0; k < CH; k++) v[k] = __builtin_nontemporal_load(s + (size_t)k * SK_TILE);
-#pragma unroll
-    for (int k = 0; k < CH; k++) LW(4 * k + 0) = v[k].x, LW(4 * k + 1) = v[k].y, LW(4 * k + 2) = v[k].z, LW(4 * k + 3) = v[k].w;
-  } else {
-    const int n = P.L.chunks;
-    for (int c = 0; c < n; c += 6) {
-      sk_u32x4_nt v[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++)
-        if (c + k < n) v[k] = __builtin_nontemporal_load(s + (size_t)(c + k) * SK_TILE);
-#pragma unroll
-      for (int k = 0; k < 6; k++)
-        if (c + k < n) {
-          const int w = 4 * (c + k);
-          LW(w + 0) = v[k].x, LW(w + 1) = v[k].y, LW(w + 2) = v[k].z, LW(w + 3) = v[k].w;
-        }
-    }
-  }
-}
 __device__ __forceinline__ void tile_store_nt(const SkParams &P, uint4 *dst, int tile, int lane, uint8_t *lp) {
   sk_u32x4_nt *d = (sk_u32x4_nt *)(dst + (size_t)tile * P.L.chunks * SK_TILE + lane);
   const int n = P.L.chunks;
   for (int c = 0; c < n; c += 6) {
-    sk_u32x4_nt v[6];
+    uint4 v[6];
 #pragma unroll
     for (int k = 0; k < 6; k++)
-      if (c + k < n) {
-        const int w = 4 * (c + k);
-        v[k] = (sk_u32x4_nt){LW(w + 0), LW(w + 1), LW(w + 2), LW(w + 3)};
-      }
+      if (c + k < n) v[k] = LQ(c + k);
 #pragma unroll
     for (int k = 0; k < 6; k++)
-      if (c + k < n) __builtin_nontemporal_store(v[k], d + (size_t)(c + k) * SK_TILE);
+      if (c + k < n) __builtin_nontemporal_store((sk_u32x4_nt){v[k].x, v[k].y, v[k].z, v[k].w}, d + (size_t)(c + k) * SK_TILE);
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA: a record in tile layout (chunk c of this lane at  base + voff + c * 1024  bytes in memory) is requested
+// straight into the lane's LDS slot (chunk c at  lds_tile + c * 1024 + lane * 16): global_load_lds_dwordx4 writes
+// M0 + offset + lane * 16 and applies its immediate offset to both addresses, so memory layout == LDS layout and a
+// record costs one instruction per chunk, no registers and no LDS-write instructions.  Lanes that are switched off
+// (EXEC) neither load nor write: a wavefront resets only the lanes whose game has ended, while the others keep playing
+// in their own columns of the tile.  The compiler does not count these loads (inline asm, no destination register):
+// whoever reads the slot calls sk_vm_drain() first.  M0 is saved and restored around each statement.
+// ------------------------------------------------------------------------------------------
+#define SK_DMA4(NT)                                                                                                     \
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                                                    \
+               "global_load_lds_dwordx4 %1, %2" NT "\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024" NT "\n\t"           \
+               "global_load_lds_dwordx4 %1, %2 offset:2048" NT "\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072" NT "\n\t" \
+               "s_mov_b32 m0, %0"                                                                                       \
+               : "=&s"(keep)                                                                                            \
+               : "v"(voff), "s"(base), "s"(lds)                                                                         \
+               : "memory")
+#define SK_DMA1(NT)                                                                                              \
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" NT "\n\ts_mov_b32 m0, %0" \
+               : "=&s"(keep)                                                                                     \
+               : "v"(voff), "s"(base), "s"(lds)                                                                  \
+               : "memory")
+template <bool NT>
+__device__ __forceinline__ void dma_record(const uint8_t *base, uint32_t voff, uint32_t lds, int chunks) {
+  uint32_t keep;
+  int c = 0;
+  for (; c + 4 <= chunks; c += 4) {
+    if (NT) SK_DMA4(" nt");
+    else SK_DMA4("");
+    base += 4096, lds += 4096;
+  }
+  for (; c < chunks; c++) {
+    if (NT) SK_DMA1(" nt");
+    else SK_DMA1("");
+    base += 1024, lds += 1024;
+  }
+}
+// every vector-memory operation this wavefront has issued so far is complete (the LDS-DMA data is in LDS)
+__device__ __forceinline__ void sk_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Diagnostic builds (-DSK_STAMPS) sum s_memtime deltas per section into P.stamps; the shipped build has none.
 struct Stamps {
@@ -397,9 +410,9 @@ __device__ __forceinline__ int pile_addr(int region_b, int k) { return region_b 
 // min over players of revealed sums / hidden counts -> obs[0], obs[1] (skyjo.py:182-183)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void refresh_minima(const SkParams &P, uint8_t *lp) {
-  int ms = LSH(P.L.off_sums), mh = LB(P.L.off_hidden);
+  int ms = LSH(sk_pb(P.L, 0) + PB_SUM), mh = LB(sk_pb(P.L, 0) + PB_HIDDEN);
   for (int q = 1; q < P.L.N; q++) {
-    int s = LSH(P.L.off_sums + 2 * q), h = LB(P.L.off_hidden + q);
+    int s = LSH(sk_pb(P.L, q) + PB_SUM), h = LB(sk_pb(P.L, q) + PB_HIDDEN);
     ms = s < ms ? s : ms, mh = h < mh ? h : mh;
   }
   LB(H_MINSUM) = (uint8_t)(int8_t)(ms < 127 ? ms : 127);
@@ -440,6 +453,11 @@ __device__ __forceinline__ bool wait_deal_done(const SkParams &P, int g) {
     f = __hip_atomic_load(&P.done_flag[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((f & 0x7fffffffu) == P.deal_tag) break;
     __builtin_amdgcn_s_sleep(32);
+  }
+  if ((f & 0x7fffffffu) != P.deal_tag) {
+    // The dealing launch never showed up (it is not resident beside this kernel and this kernel cannot end before it
+    // starts): give up loudly.  The sticky word makes skyjo_vec_get_counters fail; results after this point are void.
+    atomicOr(P.dev_error, SK_ERR_DEAL_TIMEOUT);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return (f >> 31) != 0;
@@ -518,10 +536,16 @@ __device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *l
 // _evaluate_game + _calc_final_rewards (skyjo.py:477-498, skyjo_env.py:293-312), float64, no FMA
 // contraction (compiled with -ffp-contract=off), numpy's pairwise summation order for the mean.
 // ------------------------------------------------------------------------------------------
-// per-lane float64 accumulators behind the RNG scratch: element k of lane l at ap + k * 512 (ap = base + l * 8)
-#define ACC(k) (*(double *)(ap + ((k) << 9)))
+// Per-WAVEFRONT float64 statistics (SK_ACC_KINDS x N doubles behind the record staging area): seat p of kind k at
+// ap + (k * N + p) * 8.  Only lanes whose game has just ended add to them (about one lane every second iteration),
+// as fire-and-forget LDS atomics - the few lanes that meet on one address are serialised by the LDS unit.
+#define ACC(k) (*(double *)(ap + ((k) << 3)))
 __device__ __forceinline__ void acc_add(uint8_t *ap, int k, double v) {
   __hip_atomic_fetch_add(&ACC(k), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ void acc_episode(uint8_t *ap, int N, int p, double score, double reward, int refunded) {
+  acc_add(ap, p, score), acc_add(ap, N + p, reward), acc_add(ap, 2 * N + p, reward * reward);
+  if (refunded) acc_add(ap, 3 * N + p, (double)refunded);
 }
 
 __device__ __forceinline__ void finish_game(const SkParams &P, uint8_t *lp, uint8_t *fp, uint8_t *ap, int g,
@@ -533,7 +557,7 @@ __device__ __forceinline__ void finish_game(const SkParams &P, uint8_t *lp, uint
   for (int p = 0; p < N; p++) {
     int s = 0;
     for (int c = 0; c < 4; c++) {
-      int b = P.L.off_cards + 12 * p + 3 * c;
+      int b = sk_pb(P.L, p) + PB_CARDS + 3 * c;
       int t0 = LI(b), t1 = LI(b + 1), t2 = LI(b + 2);
       if (!(t0 == t1 && t1 == t2)) s += t0 + t1 + t2;  // skyjo.py:488-493, hidden cards included
     }
@@ -555,9 +579,10 @@ __device__ __forceinline__ void finish_game(const SkParams &P, uint8_t *lp, uint
   for (int p = 0; p < N; p++) {
     const double d = SCORE(p);
     double r = (-d + mean) + P.mean_reward;
-    if (P.reward_refunded != 0.0) r += (double)LB(P.L.off_refunded + p) * P.reward_refunded;
+    const int rf = LB(sk_pb(P.L, p) + PB_REFUNDED);
+    if (P.reward_refunded != 0.0) r += (double)rf * P.reward_refunded;
     sc[p] = d, rw[p] = r;
-    acc_add(ap, p, d), acc_add(ap, N + p, r);
+    acc_episode(ap, N, p, d, r, rf);
   }
 #undef SCORE
   P.done[g] = 1;
@@ -571,9 +596,9 @@ __device__ __forceinline__ void finish_game_fixed(const SkParams &P, uint8_t *lp
   int mn = 0, fs = 0;
 #pragma unroll
   for (int p = 0; p < NP; p++) {
-    const int cw = (P.L.off_cards + 12 * p) >> 2;
-    const uint32_t c0 = LW(cw), c1 = LW(cw + 1), c2 = LW(cw + 2);
-    refunded[p] = LB(P.L.off_refunded + p);
+    const uint4 row = LQ(sk_pb(P.L, p) >> 4);  // cards + the player's counters in one read
+    const uint32_t c0 = row.x, c1 = row.y, c2 = row.z;
+    refunded[p] = (int)(row.w >> 24);
     const uint32_t tri[4] = {c0 & 0xffffffu, (c0 >> 24) | ((c1 & 0xffffu) << 8), (c1 >> 16) | ((c2 & 0xffu) << 16), c2 >> 8};
     int t = 0;
 #pragma unroll
@@ -598,7 +623,7 @@ __device__ __forceinline__ void finish_game_fixed(const SkParams &P, uint8_t *lp
     double r = (-d[p] + mean) + P.mean_reward;
     if (P.reward_refunded != 0.0) r += (double)refunded[p] * P.reward_refunded;
     sc[p] = d[p], rw[p] = r;
-    acc_add(ap, p, d[p]), acc_add(ap, NP + p, r);
+    acc_episode(ap, NP, p, d[p], r, refunded[p]);
   }
   P.done[g] = 1;
 }
@@ -628,7 +653,7 @@ __device__ __forceinline__ void put3(uint32_t &a, uint32_t &b, uint32_t &c, int 
 }
 __device__ __forceinline__ void hist_add(uint8_t *lp, int value, int delta) {  // bins live at bytes 18..32
   const int b = H_HIST + 2 + value;
-  uint32_t *w = (uint32_t *)(lp + ((b >> 2) << 8));
+  uint32_t *w = (uint32_t *)(lp + LIDX(b & ~3));
   const uint32_t d = (uint32_t)delta << ((b & 3) * 8);
   __hip_atomic_fetch_add(w, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
@@ -648,8 +673,8 @@ struct ObsRegs {
   uint32_t q0, q1, q2, nz0, nz1, nz2, hd0, hd1, hd2;
 };
 __device__ __forceinline__ void obs_load(const SkParams &P, uint8_t *lp, int q, ObsRegs &o) {
-  const int vq = (P.L.off_vis + 12 * q) >> 2;
-  o.q0 = LW(vq), o.q1 = LW(vq + 1), o.q2 = LW(vq + 2);
+  const uint4 row = LQ((sk_pb(P.L, q) + PB_VIS) >> 4);  // (the fourth word is the placed counter)
+  o.q0 = row.x, o.q1 = row.y, o.q2 = row.z;
   o.nz0 = swar_nonzero01(o.q0 ^ 0xf2f2f2f2u);  // vis != -14  <=> players_masked != 0
   o.nz1 = swar_nonzero01(o.q1 ^ 0xf2f2f2f2u);
   o.nz2 = swar_nonzero01(o.q2 ^ 0xf2f2f2f2u);
@@ -694,7 +719,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
                                              uint32_t v1, uint32_t v2, int a, int g, LaneCounters &cnt, Stamps &st) {
   const int N = P.L.N;
   const int phase = h.w0 & 0xff, p = (h.w0 >> 8) & 0xff;
-  const int cardb = P.L.off_cards + 12 * p, visb = cardb + 12 * N, pb = P.L.off_pile;
+  const int blk = sk_pb(P.L, p), cardb = blk + PB_CARDS, visb = blk + PB_VIS, pb = P.L.off_pile;
   const unsigned ua = (unsigned)a;
   int slot = 0, sv = 0;
   bool legal;
@@ -708,7 +733,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
   if (!legal) {  // offender gets illegal_reward, everybody else 0, all done
     double *rw = P.rewards + (size_t)g * N;
     for (int q = 0; q < N; q++) rw[q] = q == p ? P.illegal_reward : 0.0;
-    acc_add(ap, N + p, P.illegal_reward);
+    acc_add(ap, N + p, P.illegal_reward), acc_add(ap, 2 * N + p, P.illegal_reward * P.illegal_reward);
     h.w0 = (h.w0 & 0x0000ffffu) | ((((h.w0 >> 16) & 0xffu) | F_DONE) << 16) | ((uint32_t)SKYJO_ST_ILLEGAL << 24);
     P.done[g] = 1;
     cnt.illegal++;
@@ -724,7 +749,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
     const int role = (h.w1 >> 16) & 1;
     int nd = h.w1 & 0xff;
     const int ns = (h.w1 >> 8) & 0xff;
-    const int hidden_p = LB(P.L.off_hidden + p);
+    const int hidden_p = LB(blk + PB_HIDDEN);
     int pile_top = LI(pb + pile_addr(role, nd > 0 ? nd - 1 : 0));
     const int disc_top = LI(pb + pile_addr(role ^ 1, ns > 0 ? ns - 1 : 0));
     const int disc_below = LI(pb + pile_addr(role ^ 1, ns > 1 ? ns - 2 : 0));
@@ -773,13 +798,14 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
   const int hand = (int)(int8_t)(h.w2 >> 24);
   const int reg = ((h.w1 >> 16) & 1) ^ 1;
   int ns = (h.w1 >> 8) & 0xff;
-  const int cw = cardb >> 2;
-  const uint32_t c0 = LW(cw), c1 = LW(cw + 1), c2 = LW(cw + 2);
-  int sum = LSH(P.L.off_sums + 2 * p), hid = LB(P.L.off_hidden + p);
+  const uint4 row = LQ(blk >> 4);  // the acting player's cards and his counters: one read
+  const uint32_t c0 = row.x, c1 = row.y, c2 = row.z;
+  int sum = (int)(int16_t)(row.w & 0xffffu), hid = (int)((row.w >> 16) & 0xffu), refunded = (int)(row.w >> 24);
   // minima over the OTHER players do not change in this turn (skyjo.py:182-183)
   int oms = 1 << 20, omh = 1 << 20;
   for (int q = 0; q < N; q++) {
-    const int s = LSH(P.L.off_sums + 2 * q), hq = LB(P.L.off_hidden + q);
+    const uint32_t cq = LW((sk_pb(P.L, q) + PB_SUM) >> 2);
+    const int s = (int)(int16_t)(cq & 0xffffu), hq = (int)((cq >> 16) & 0xffu);
     oms = (q != p && s < oms) ? s : oms, omh = (q != p && hq < omh) ? hq : omh;
   }
 #ifdef SK_STAMPS_FINE
@@ -832,15 +858,13 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
           sum -= 3 * t0;
           top = 0;
         }
-      LB(P.L.off_refunded + p)++;  // +1 per action, not per column (skyjo.py:418-419)
+      refunded++;  // +1 per action, not per column (skyjo.py:418-419)
     }
   }
-  LSH(P.L.off_sums + 2 * p) = (int16_t)sum;
-  LB(P.L.off_hidden + p) = (uint8_t)hid;
-  {  // num_placed[p]++ (skyjo.py:424) as a fire-and-forget add on the dword that holds the u16: no read, no wait
-    const int b = P.L.off_placed + 2 * p;
-    __hip_atomic_fetch_add((uint32_t *)(lp + ((b >> 2) << 8)), 1u << ((b & 2) * 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  }
+  // sum / hidden / refunded of the acting player go back as one word
+  LW((blk + PB_SUM) >> 2) = ((uint32_t)sum & 0xffffu) | ((uint32_t)hid << 16) | ((uint32_t)refunded << 24);
+  // num_placed[p]++ (skyjo.py:424) as a fire-and-forget add on the dword that holds the u16: no read, no wait
+  __hip_atomic_fetch_add((uint32_t *)(lp + LIDX(blk + PB_PLACED)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   const int ms = sum < oms ? sum : oms, mh = hid < omh ? hid : omh;
   LB(H_MINSUM) = (uint8_t)(int8_t)(ms < 127 ? ms : 127);
   LB(H_MINHID) = (uint8_t)mh;
@@ -857,10 +881,11 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
 // order (direct, skyjo.py:279-302).
 // ------------------------------------------------------------------------------------------
 template <bool INDIRECT>
-__device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, const HdrRegs &h, const ObsRegs &ob, uint8_t *out,
-                                            uint4 *held = nullptr) {
+__device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, const HdrRegs &h, const ObsRegs &ob, int action,
+                                            uint8_t *out, uint4 *held = nullptr) {
   const int phase = h.w0 & 0xff;
   const uint32_t q0 = ob.q0, q1 = ob.q1, q2 = ob.q2;
+  const uint32_t act24 = ((uint32_t)action & 0xffu) << 24;  // byte D of the record: the action this step applied (-1: none)
   uint32_t m[8];
   {
     // (computed in both phases and masked: a branch on the phase measured 2 us slower per launch)
@@ -869,13 +894,13 @@ __device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, cons
     m[6] = (phase ? 0u : 0x0101u) | (((h.w0 >> 8) & 0xffu) << 16) | ((uint32_t)phase << 24);
     m[7] = (((h.w0 >> 16) & F_DONE) ? 1u : 0u) | ((h.w0 >> 24) << 8) | ((h.w2 & 0xffffu) << 16);
   }
-  // obs[16] = hist[14], obs[17] = discard top, obs[18] = hand card
-  const uint32_t s8 = (LW(8) & 0xffu) | ((h.w1 >> 24) << 8) | ((h.w2 >> 24) << 16);
+  // obs[0..15] are chunk 1 of the record; obs[16] = hist[14], obs[17] = discard top, obs[18] = hand card
+  const uint4 a = LQ(1);
+  const uint32_t s8 = (uint32_t)LB(32) | ((h.w1 >> 24) << 8) | ((h.w2 >> 24) << 16);
   if (INDIRECT) {
     uint4 *o = (uint4 *)out;
-    uint4 a, b;
-    a.x = LW(4), a.y = LW(5), a.z = LW(6), a.w = LW(7);
-    b.x = s8 | (q0 << 24), b.y = (q0 >> 8) | (q1 << 24), b.z = (q1 >> 8) | (q2 << 24), b.w = q2 >> 8;
+    uint4 b;
+    b.x = s8 | (q0 << 24), b.y = (q0 >> 8) | (q1 << 24), b.z = (q1 >> 8) | (q2 << 24), b.w = (q2 >> 8) | act24;
     if (held) {  // the caller stores the record itself
       held[0] = a, held[1] = b, held[2] = make_uint4(m[0], m[1], m[2], m[3]), held[3] = make_uint4(m[4], m[5], m[6], m[7]);
     } else {
@@ -884,16 +909,20 @@ __device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, cons
       o[3] = make_uint4(m[4], m[5], m[6], m[7]);
     }
   } else {
+    // direct observation (skyjo.py:279-302): every player's visible row in absolute seat order, 12 bytes each, packed
+    // behind obs[18]; a row is one chunk read
     uint32_t *o = (uint32_t *)out;
-    const int nv = 3 * P.L.N, v0 = P.L.off_vis >> 2;
-    for (int w = 0; w < 4; w++) o[w] = LW(4 + w);
-    uint32_t prev = LW(v0);
-    o[4] = s8 | (prev << 24);
-    for (int j = 0; j < nv; j++) {
-      uint32_t nxt = j + 1 < nv ? LW(v0 + j + 1) : 0u;
-      o[5 + j] = (prev >> 8) | (nxt << 24);
-      prev = nxt;
+    const int N = P.L.N;
+    o[0] = a.x, o[1] = a.y, o[2] = a.z, o[3] = a.w;
+    uint32_t carry = s8;  // three bytes waiting for the next word's top byte
+    for (int p = 0; p < N; p++) {
+      const uint4 r = LQ((sk_pb(P.L, p) + PB_VIS) >> 4);
+      o[4 + 3 * p] = carry | (r.x << 24);
+      o[5 + 3 * p] = (r.x >> 8) | (r.y << 24);
+      o[6 + 3 * p] = (r.y >> 8) | (r.z << 24);
+      carry = r.z >> 8;
     }
+    o[4 + 3 * N] = carry | act24;
     uint32_t *om = o + (P.L.Dp >> 2);
 #pragma unroll
     for (int w = 0; w < 8; w++) om[w] = m[w];
@@ -915,76 +944,55 @@ __device__ __forceinline__ void bank_advance(const SkParams &P, uint8_t *lp, int
   P.done[g] = 0;
 }
 
-__device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, int tile, int lane, int g) {
+// k_reset / generic form: plain loads, the record passes through registers.  Returns false (slot untouched) when the
+// bank is empty.
+__device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, int tile, int lane, int g, int head) {
   const size_t G = (size_t)P.tiles * SK_TILE;
-  const int head = LB(H_BANK) % SK_BANK;
-  const uint4 *s = P.spare + ((size_t)head * P.tiles + tile) * P.L.chunks * SK_TILE + lane;
-  const int n = P.L.chunks;
-  // flags and the first 9 chunks are requested together (the record is read even if it turns out not to be ready)
   const uint8_t ready = P.spare_ready[(size_t)head * G + g];
   const uint32_t dc = P.deals_consumed[g];
-  uint4 v[9];
-#pragma unroll
-  for (int k = 0; k < 9; k++)
-    if (k < n) v[k] = s[(size_t)k * SK_TILE];
   if (!ready) return false;
-#pragma unroll
-  for (int k = 0; k < 9; k++)
-    if (k < n) LW(4 * k + 0) = v[k].x, LW(4 * k + 1) = v[k].y, LW(4 * k + 2) = v[k].z, LW(4 * k + 3) = v[k].w;
-  for (int c = 9; c < n; c += 9) {
-#pragma unroll
-    for (int k = 0; k < 9; k++)
-      if (c + k < n) v[k] = s[(size_t)(c + k) * SK_TILE];
-#pragma unroll
-    for (int k = 0; k < 9; k++)
-      if (c + k < n) {
-        const int w = 4 * (c + k);
-        LW(w + 0) = v[k].x, LW(w + 1) = v[k].y, LW(w + 2) = v[k].z, LW(w + 3) = v[k].w;
-      }
-  }
+  load_spare(P, lp, head, tile, lane);
   P.spare_ready[(size_t)head * G + g] = 0;  // k_scan finds the banks that are not full
   bank_advance(P, lp, g, head, dc);
   return true;
 }
 
-// The same in two halves for the step kernel (compile-time chunk count): `spare_issue` requests the whole
-// record, `spare_commit` lands it.  Between the two the wavefront steps its live games, which hides the
-// HBM round trip of the few lanes that are resetting (about every second iteration has one).
-// LDS stride of one staged record: the record's own size, plus 16 bytes when that is a multiple of 32 dwords / 4 - the
-// lane-per-record dword writes then spread over 8 banks groups instead of 4.
-__device__ __forceinline__ constexpr int sk_stage_stride(int rec_bytes) { return ((rec_bytes >> 2) & 7) == 0 ? rec_bytes + 16 : rec_bytes; }
-constexpr int sk_chunks_of(int N) { return ((((H_END + 6 * N + 3) & ~3) + 24 * N + SK_NCARDS + 15) & ~15) / 16; }
-template <int CH>
+// The step kernel's form, in two halves.  `spare_issue` asks for the whole record by LDS-DMA straight into the lane's
+// own (dead: its game is over) slot of the tile - no registers, no LDS writes - and for the two words of bookkeeping;
+// `spare_commit` waits for everything this wavefront has in flight and finishes the hand-over.  Between the two the
+// wavefront steps its live games, which hides the memory round trip of the few lanes that are resetting (about every
+// second iteration has one).  If the bank turns out to be empty the slot holds a stale record: the caller deals in
+// place, which rewrites every word of it.
 struct SpareRegs {
-  uint4 v[CH];
   uint32_t dc;
   int head;
   uint8_t ready;
 };
-template <int CH>
-__device__ __forceinline__ void spare_issue(const SkParams &P, uint8_t *lp, int tile, int lane, int g, SpareRegs<CH> &r) {
+__device__ __forceinline__ void spare_issue(const SkParams &P, uint8_t *lp, uint32_t lds_tile, int tile, int lane, int g, SpareRegs &r) {
   const size_t G = (size_t)P.tiles * SK_TILE;
-  r.head = LB(H_BANK) % SK_BANK;
-  const uint4 *s = P.spare + ((size_t)r.head * P.tiles + tile) * CH * SK_TILE + lane;
+  r.head = LB(H_BANK) % SK_BANK;  // (read before the record is overwritten)
   r.ready = P.spare_ready[(size_t)r.head * G + g];
   r.dc = P.deals_consumed[g];
-#pragma unroll
-  for (int k = 0; k < CH; k++) r.v[k] = s[(size_t)k * SK_TILE];
+  const uint32_t voff = (uint32_t)((((size_t)r.head * P.tiles + tile) * P.L.chunks * SK_TILE + lane) * 16);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the old record has returned
+  dma_record<false>((const uint8_t *)P.spare, voff, lds_tile, P.L.chunks);
 }
-template <int CH>
-__device__ __forceinline__ bool spare_commit(const SkParams &P, uint8_t *lp, int g, const SpareRegs<CH> &r) {
+__device__ __forceinline__ bool spare_commit(const SkParams &P, uint8_t *lp, int g, const SpareRegs &r) {
+  sk_vm_drain();
   if (!r.ready) return false;
-#pragma unroll
-  for (int k = 0; k < CH; k++) LW(4 * k + 0) = r.v[k].x, LW(4 * k + 1) = r.v[k].y, LW(4 * k + 2) = r.v[k].z, LW(4 * k + 3) = r.v[k].w;
   P.spare_ready[(size_t)r.head * (size_t)P.tiles * SK_TILE + g] = 0;  // k_scan finds the banks that are not full
   bank_advance(P, lp, g, r.head, r.dc);
   return true;
 }
 
+// LDS stride of one staged record: the record's own size, plus 16 bytes when that is a multiple of 32 dwords / 4 - the
+// lane-per-record dword writes then spread over 8 banks groups instead of 4.
+__device__ __forceinline__ constexpr int sk_stage_stride(int rec_bytes) { return ((rec_bytes >> 2) & 7) == 0 ? rec_bytes + 16 : rec_bytes; }
+
 // Fallback when the pre-dealt episode is not available inside a launch (a mid-game reshuffle just
 // invalidated it, or the game already took one in this launch): deal right here, on this lane, from
 // the game's current stream position.  Rare and slow (one lane active), never changes results.
-__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane);
+__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane, int head);
 
 // ------------------------------------------------------------------------------------------
 // k_step: `iters` lockstep iterations over all tiles.  POLICY=false: one iteration with the
@@ -992,6 +1000,8 @@ __device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint
 // ------------------------------------------------------------------------------------------
 // NP > 0 fixes the player count at compile time (2, 3 and 4 are instantiated): every record offset becomes
 // an immediate and the per-player loops unroll; NP == 0 is the generic kernel for any 1..12 players.
+// SKYJO_ACTION_SKIP as a caller action leaves the game exactly as it is (no step, no reset; its record is still
+// written): that is how the single-game views step ONE game of a shared engine.
 template <bool INDIRECT, bool POLICY, int NP>
 __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *actions, uint8_t *rec_out,
                                                   int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0) {
@@ -999,13 +1009,20 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   if (NP > 0) P.L = sk_make_layout(NP, INDIRECT ? 1 : 0);  // same values as the host computed, now constants
   extern __shared__ uint32_t lds_raw[];
   const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
-  uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
-  uint8_t *fp = lp + P.L.chunks * 1024;  // 16-word per-lane scratch behind the tile (RNG FIFO)
-  uint8_t *ap = (uint8_t *)lds_raw + P.L.chunks * 1024 + 4096 + lane * 8;  // 2N float64 accumulators per lane
-  uint8_t *stg = (uint8_t *)lds_raw + P.L.chunks * 1024 + 4096 + 2 * P.L.N * 512;  // 4 KiB: one iteration's records
-  for (int k = 0; k < 2 * P.L.N; k++) ACC(k) = 0.0;
+  const uint32_t lds_tile = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_raw;
+  uint8_t *lp = (uint8_t *)lds_raw + lane * 16;
+  // LDS map: the tile | one iteration's records (4 KiB for the 64-byte records) | the wavefront's statistics.  The 16-word
+  // per-lane scratch of the rare paths (RNG FIFO of a mid-game reshuffle / an in-place deal) ALIASES the record staging
+  // area: those paths run inside the step, before this iteration's records are staged and after the previous
+  // iteration's were read back (LDS executes a wavefront's accesses in order).
+  uint8_t *stg = (uint8_t *)lds_raw + P.L.chunks * 1024;
+  uint8_t *fp = stg + lane * 4;
+  uint8_t *ap = stg + (INDIRECT ? 4096 : SK_TILE * (P.L.rec_bytes + 16));
+  if (lane < SK_ACC_KINDS * P.L.N) ACC(lane) = 0.0;
   STAMP_DECL;
-  tile_load_nt<(NP > 0 ? sk_chunks_of(NP > 0 ? NP : 1) : 0)>(P, P.state, tile, lane, lp);
+  // the tile comes in by LDS-DMA as well (non-temporal: it is read once per launch)
+  dma_record<true>((const uint8_t *)P.state, (uint32_t)((((size_t)tile * P.L.chunks) * SK_TILE + lane) * 16), lds_tile, P.L.chunks);
+  sk_vm_drain();
   HdrRegs h;
   HDR_LOAD(h);
   STAMP(0);
@@ -1023,17 +1040,17 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
     int a = -1;
     if (valid) {
       const bool over = ((h.w0 >> 16) & F_DONE) != 0;
-      constexpr int CH = NP > 0 ? sk_chunks_of(NP > 0 ? NP : 1) : 1;
-      SpareRegs<CH> sp;
-      if (NP > 0 && over && P.auto_reset) spare_issue<CH>(P, lp, tile, lane, g, sp);  // lands after the live games' step
-      if (!over) {
+      if (!POLICY) a = actions[g];
+      const bool skip = !POLICY && a == SKYJO_ACTION_SKIP;
+      SpareRegs sp;
+      const bool resetting = over && P.auto_reset && !skip;
+      if (resetting) spare_issue(P, lp, lds_tile, tile, lane, g, sp);  // lands while the live games step
+      if (!over && !skip) {
         const uint32_t v0 = ob.q0, v1 = ob.q1, v2 = ob.q2;  // the acting player's row, read for the previous record
         STAMP(2);
         if (POLICY) {
           const uint32_t sel = (uint32_t)(iter & 3);
           a = policy_pick(h.w0 & 0xff, ob, sel == 0 ? r0 : sel == 1 ? r1 : sel == 2 ? r2 : r3);
-        } else {
-          a = actions[g];
         }
 #ifndef SK_STAMPS_FINE
         STAMP(3);
@@ -1044,11 +1061,12 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
 #else
         STAMP(5);
 #endif
-      } else {
+      } else if (!skip) {
+        a = -1;
         if (P.auto_reset) {
-          if (!(NP > 0 ? spare_commit<CH>(P, lp, g, sp) : consume_spare(P, lp, tile, lane, g))) {
+          if (!spare_commit(P, lp, g, sp)) {
 #ifndef SK_EXPERIMENT_NO_RARE
-            deal_inline(P, lp, fp, g, tile, lane);
+            deal_inline(P, lp, fp, g, tile, lane, sp.head);
 #endif
             cnt.waits++;  // counts the slow-path deals
           }
@@ -1059,16 +1077,18 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
           h.w0 = (h.w0 & 0x00ffffffu) | ((uint32_t)SKYJO_ST_NOOP_DONE << 24);
         }
         STAMP(1);
+      } else {
+        a = -1;
       }
       obs_load(P, lp, (h.w0 >> 8) & 0xff, ob);  // one read of the row serves this record and the next iteration's turn
       if (rec_out) {
         if (INDIRECT) {  // staged in LDS, written by the whole wavefront below
           uint4 rr[4];
-          emit_record<INDIRECT>(P, lp, h, ob, nullptr, rr);
+          emit_record<INDIRECT>(P, lp, h, ob, a, nullptr, rr);
 #pragma unroll
           for (int p = 0; p < 4; p++) *(uint4 *)(stg + lane * 64 + ((p + (lane >> 1)) & 3) * 16) = rr[p];
         } else {  // direct observation: rec_bytes = 80 / 96 / 112 ...; staged record-major with a stride that spreads the banks
-          emit_record<INDIRECT>(P, lp, h, ob, stg + lane * sk_stage_stride(P.L.rec_bytes));
+          emit_record<INDIRECT>(P, lp, h, ob, a, stg + lane * sk_stage_stride(P.L.rec_bytes));
         }
       }
       if (act_out) __builtin_nontemporal_store(a, &act_out[(size_t)it * P.B + g]);
@@ -1120,17 +1140,10 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
 #pragma unroll
     for (int k = 0; k < 7; k++) c[k] += v[k];
   }
-  // per-seat score / reward sums of this launch: wavefront reduction, then one slot per tile
+  // per-seat statistics of this launch: one slot per tile
   if (__any(cnt.episodes | cnt.illegal)) {
-    double mine = 0.0;
-    for (int k = 0; k < 2 * P.L.N; k++) {
-      double x = ACC(k);
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-      x = __shfl(x, 0, 64);
-      mine = lane == k ? x : mine;
-    }
-    if (lane < 2 * P.L.N)  // scores in slots 0..11, rewards in 12..23
-      P.acc_tile[(size_t)tile * 2 * SKYJO_MAX_PLAYERS + (lane < P.L.N ? lane : SKYJO_MAX_PLAYERS + lane - P.L.N)] += mine;
+    if (lane < SK_ACC_KINDS * P.L.N)  // lane = kind * N + seat -> slot kind * 12 + seat of the tile
+      P.acc_tile[(size_t)tile * SK_ACC_KINDS * SKYJO_MAX_PLAYERS + (lane / P.L.N) * SKYJO_MAX_PLAYERS + lane % P.L.N] += ACC(lane);
   }
   STAMP(7);
   STAMP_STORE;
@@ -1141,7 +1154,7 @@ template <bool INDIRECT>
 __global__ __launch_bounds__(SK_TILE) void k_observe(SkParams P, const int32_t *players, uint8_t *rec_out) {
   extern __shared__ uint32_t lds_raw[];
   const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
-  uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
+  uint8_t *lp = (uint8_t *)lds_raw + lane * 16;
   tile_load(P, P.state, tile, lane, lp);
   if (!(LB(H_FLAGS) & F_VALID)) return;
   HdrRegs h;
@@ -1150,7 +1163,7 @@ __global__ __launch_bounds__(SK_TILE) void k_observe(SkParams P, const int32_t *
   q = q < 0 ? 0 : (q >= P.L.N ? P.L.N - 1 : q);
   ObsRegs ob;
   obs_load(P, lp, q, ob);
-  emit_record<INDIRECT>(P, lp, h, ob, rec_out + (size_t)g * P.L.rec_bytes);
+  emit_record<INDIRECT>(P, lp, h, ob, -1, rec_out + (size_t)g * P.L.rec_bytes);
 }
 
 // SkyjoGame.reset for the masked games: take the pre-dealt episode.
@@ -1158,13 +1171,14 @@ template <bool INDIRECT>
 __global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *mask, uint8_t *rec_out) {
   extern __shared__ uint32_t lds_raw[];
   const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
-  uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
-  uint8_t *fp = lp + P.L.chunks * 1024;
+  uint8_t *lp = (uint8_t *)lds_raw + lane * 16;
+  uint8_t *fp = (uint8_t *)lds_raw + P.L.chunks * 1024 + lane * 4;
   if (g >= P.B) return;
   const bool want = !mask || mask[g];
-  tile_load(P, P.state, tile, lane, lp);  // (the bank pointer of the game lives in its record)
+  tile_load(P, P.state, tile, lane, lp);
   if (want) {
-    if (!consume_spare(P, lp, tile, lane, g)) deal_inline(P, lp, fp, g, tile, lane);
+    const int head = P.bank_head[g] % SK_BANK;
+    if (!consume_spare(P, lp, tile, lane, g, head)) deal_inline(P, lp, fp, g, tile, lane, head);
     LB(H_STATUS) = SKYJO_ST_RESET;
   }
   HdrRegs h;
@@ -1172,7 +1186,7 @@ __global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *ma
   if (rec_out) {
     ObsRegs ob;
     obs_load(P, lp, LB(H_PLAYER), ob);
-    emit_record<INDIRECT>(P, lp, h, ob, rec_out + (size_t)g * P.L.rec_bytes);
+    emit_record<INDIRECT>(P, lp, h, ob, -1, rec_out + (size_t)g * P.L.rec_bytes);
   }
   if (want) tile_store(P, P.state, tile, lane, lp);
   const unsigned long long wb = __ballot(want);
@@ -1521,10 +1535,10 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_ra
     }
   }
   // ---- assemble the record (skyjo_layout.h) in registers ----
-  uint32_t rec[18 * 4 + 8];
+  uint32_t rec[20 * 4];
   const int nwords = L.chunks * 4;
 #pragma unroll
-  for (int w = 0; w < 18 * 4 + 8; w++) rec[w] = 0;
+  for (int w = 0; w < 20 * 4; w++) rec[w] = 0;
   auto setb = [&](int off, uint32_t val) { rec[off >> 2] |= (val & 0xffu) << ((off & 3) * 8); };
   auto pack4 = [&](int k) {  // deck cards k .. k+3 as four bytes (cards beyond the deck read as 0)
     uint32_t w = 0;
@@ -1541,15 +1555,15 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_ra
     const int c0 = (int)(int8_t)DKW(12 * p + s0), c1 = (int)(int8_t)DKW(12 * p + s1), sum = c0 + c1;
     if (sum > bs) bs = sum, best = p;  // first argmax of revealed sums (skyjo.py:105-125)
     ms = sum < ms ? sum : ms;
-    setb(L.off_sums + 2 * p, (uint32_t)sum), setb(L.off_sums + 2 * p + 1, (uint32_t)(sum >> 8));
-    setb(L.off_hidden + p, 10);
+    const int blk = sk_pb(L, p) >> 2;  // word index of the player's block: cards[3], counters, vis[3], placed
+    rec[blk + 3] = ((uint32_t)sum & 0xffffu) | (10u << 16);  // sum, hidden = 10, refunded = 0
 #pragma unroll
     for (int j = 0; j < 3; j++) {  // vis row: 15 everywhere but the two open slots; cards row-major (skyjo.py:63-65)
       uint32_t w = 0x0f0f0f0fu;
       if ((s0 >> 2) == j) w = (w & ~(0xffu << ((s0 & 3) * 8))) | (((uint32_t)c0 & 0xffu) << ((s0 & 3) * 8));
       if ((s1 >> 2) == j) w = (w & ~(0xffu << ((s1 & 3) * 8))) | (((uint32_t)c1 & 0xffu) << ((s1 & 3) * 8));
-      rec[(L.off_vis >> 2) + 3 * p + j] = w;
-      rec[(L.off_cards >> 2) + 3 * p + j] = pack4(12 * p + 4 * j);
+      rec[blk + 4 + j] = w;
+      rec[blk + j] = pack4(12 * p + 4 * j);
     }
     if (!L.indirect) {  // direct observation: open cards are counted too (skyjo.py:160,236-248)
 #pragma unroll
@@ -1564,6 +1578,7 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_ra
 #pragma unroll
     for (int w = 4; w <= 8; w++) rec[w] += (bl >> 2) == w ? 1u << ((bl & 3) * 8) : 0u;
   }
+  static_assert((H_PILE & 3) == 0, "the pile buffer starts on a word");
 #pragma unroll
   for (int d = 0; d < (SK_NCARDS + 3) / 4; d++) {  // draw pile = rest[0 .. R-2], discard pile = [rest[R-1]] at the far end
     uint32_t m = 0;
@@ -1571,7 +1586,7 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_ra
       if (4 * d + j < R - 1) m |= 0xffu << (8 * j);
     uint32_t w = m ? (pack4(12 * NP + 4 * d) & m) : 0u;
     if (d == (SK_NCARDS - 1) / 4) w |= ((uint32_t)last & 0xffu) << (((SK_NCARDS - 1) & 3) * 8);
-    rec[(L.off_pile >> 2) + d] = w;
+    rec[(H_PILE >> 2) + d] |= w;
   }
   rec[0] = (uint32_t)best << 8 | (uint32_t)F_VALID << 16 | (uint32_t)SKYJO_ST_RESET << 24;
   rec[1] = (uint32_t)(R - 1) | 1u << 8 | ((uint32_t)last & 0xffu) << 24;
@@ -1579,7 +1594,7 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_ra
   rec[3] = episode;
   setb(H_MINSUM, (uint32_t)(ms < 127 ? ms : 127)), setb(H_MINHID, 10);
 #pragma unroll
-  for (int c = 0; c < 18 + 2; c++)
+  for (int c = 0; c < 20; c++)
     if (4 * c < nwords) dst[(size_t)c * SK_TILE] = make_uint4(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]);
 }
 #undef DKW
@@ -1587,9 +1602,9 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_ra
 template <class Rng>
 __device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rng &r, uint32_t episode) {
   const int N = P.L.N, pb = P.L.off_pile, R = SK_NCARDS - 12 * N;
-  const int pw = pb >> 2, cw = P.L.off_cards >> 2;  // word indices (both regions are 4-byte aligned)
-  const int tmp = pb + R;                           // 12 free bytes behind the rest (R + 12 <= 150)
-  for (int w = 0; w < P.L.chunks * 4; w++) LW(w) = 0;
+  const int pw = pb >> 2;   // word index of the pile buffer (4-byte aligned)
+  const int tmp = pb + R;   // 12 free bytes behind the rest (R + 12 <= 150)
+  for (int c = 0; c < P.L.chunks; c++) LQ(c) = make_uint4(0u, 0u, 0u, 0u);
   // _new_drawpile: repeat(arange(-2, 13), 10) then shuffle (skyjo.py:76-82); written four cards per word
   for (int d = 0; d < (SK_NCARDS + 3) / 4; d++) {
     uint32_t w = 0;
@@ -1607,7 +1622,8 @@ __device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rn
     int base = pb, n = SK_NCARDS;
     if (seg == 1) {
       // first 12N cards row-major to players 0..N-1 (skyjo.py:63-65)
-      for (int d = 0; d < 3 * N; d++) LW(cw + d) = LW(pw + d);
+      for (int p = 0; p < N; p++)
+        for (int j = 0; j < 3; j++) LW((sk_pb(P.L, p) >> 2) + j) = LW(pw + 3 * p + j);
       // the rest is shuffled again; all but its last card form the draw pile (skyjo.py:68-70,127-138).
       // Word-wise move down by 3N words, 8 words at a time (reads of a batch precede its writes).
       for (int d = 0; d < (R + 3) / 4; d += 8) {
@@ -1622,17 +1638,18 @@ __device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rn
     } else if (seg >= 2) {
       // _reset_card_mask: two open cards per player = permutation(12)[:2] (skyjo.py:96-103)
       const int p = seg - 2;
-      for (int k = 0; k < 12; k++) LB(tmp + k) = (uint8_t)k, LB(P.L.off_vis + 12 * p + k) = SKYJO_HAND_NONE;
+      for (int k = 0; k < 12; k++) LB(tmp + k) = (uint8_t)k, LB(sk_pb(P.L, p) + PB_VIS + k) = SKYJO_HAND_NONE;
       base = tmp, n = 12;
     }
     shuffle_lds(lp, base, n, r);
     if (seg >= 2) {
       const int p = seg - 2;
       int s0 = LB(tmp), s1 = LB(tmp + 1);
-      int c0 = LI(P.L.off_cards + 12 * p + s0), c1 = LI(P.L.off_cards + 12 * p + s1);
-      LB(P.L.off_vis + 12 * p + s0) = (uint8_t)c0, LB(P.L.off_vis + 12 * p + s1) = (uint8_t)c1;
-      LSH(P.L.off_sums + 2 * p) = (int16_t)(c0 + c1);
-      LB(P.L.off_hidden + p) = 10;
+      const int blk = sk_pb(P.L, p);
+      int c0 = LI(blk + PB_CARDS + s0), c1 = LI(blk + PB_CARDS + s1);
+      LB(blk + PB_VIS + s0) = (uint8_t)c0, LB(blk + PB_VIS + s1) = (uint8_t)c1;
+      LSH(blk + PB_SUM) = (int16_t)(c0 + c1);
+      LB(blk + PB_HIDDEN) = 10;
       if (!P.L.indirect) LB(H_HIST + 2 + c0)++, LB(H_HIST + 2 + c1)++;
     }
   }
@@ -1642,9 +1659,9 @@ __device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rn
   LB(pb + SK_NCARDS - 1) = (uint8_t)last;  // discard pile = [last], stored from the far end
   LB(H_HIST + 2 + last)++;
   // _reset_start_player: first argmax of revealed sums draws first (skyjo.py:105-125)
-  int best = 0, bs = LSH(P.L.off_sums);
+  int best = 0, bs = LSH(sk_pb(P.L, 0) + PB_SUM);
   for (int p = 1; p < N; p++) {
-    int s = LSH(P.L.off_sums + 2 * p);
+    int s = LSH(sk_pb(P.L, p) + PB_SUM);
     if (s > bs) bs = s, best = p;
   }
   LB(H_PHASE) = 0, LB(H_PLAYER) = (uint8_t)best, LB(H_FLAGS) = F_VALID, LB(H_STATUS) = SKYJO_ST_RESET;
@@ -1654,9 +1671,8 @@ __device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rn
   refresh_minima(P, lp);
 }
 
-__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane) {
+__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane, int head) {
   const uint32_t ep = P.deals_consumed[g];
-  const int head = LB(H_BANK) % SK_BANK;
   const int busy = P.busy[g];
   if (busy) {
     // The bank is empty, but the dealing launch that overlaps this kernel is dealing exactly the episode needed
@@ -1781,7 +1797,7 @@ template <int NP>
 __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int publish_inline) {
   extern __shared__ uint32_t lds_raw[];
   const int lane = threadIdx.x;
-  uint8_t *lp = (uint8_t *)lds_raw + lane * 4;
+  uint8_t *lp = (uint8_t *)lds_raw + lane * 16;
   const size_t G = (size_t)P.tiles * SK_TILE;
   const int count = (int)P.deal_count[list_sel];
   const int i = blockIdx.x * SK_TILE + lane;
@@ -1820,7 +1836,7 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
         P.mt_idx[g] = r.close();
         generated = r.chunks_made * 16;
       } else {
-        uint8_t *fp = lp + P.L.chunks * 1024;
+        uint8_t *fp = (uint8_t *)lds_raw + P.L.chunks * 1024 + lane * 4;
         MtStream<64> r;
         r.open(mt, packed, fp);
         r.stp = &st;
@@ -1877,18 +1893,14 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
 
 // per-seat sums over all games for skyjo_vec_get_counters (the hot path keeps per-game sums, no atomics)
 __global__ void k_reduce_stats(SkParams P) {
-  for (int p = 0; p < P.L.N; p++) {
-    double a = 0.0, b = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.tiles; i += gridDim.x * blockDim.x) {
-      a += P.acc_tile[(size_t)i * 2 * SKYJO_MAX_PLAYERS + p];
-      b += P.acc_tile[(size_t)i * 2 * SKYJO_MAX_PLAYERS + SKYJO_MAX_PLAYERS + p];
+  for (int kind = 0; kind < SK_ACC_KINDS; kind++)
+    for (int p = 0; p < P.L.N; p++) {
+      double a = 0.0;
+      for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.tiles; i += gridDim.x * blockDim.x)
+        a += P.acc_tile[((size_t)i * SK_ACC_KINDS + kind) * SKYJO_MAX_PLAYERS + p];
+      for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+      if ((threadIdx.x & 63) == 0 && a != 0.0) atomicAdd(&P.counters->sum_score[kind * SKYJO_MAX_PLAYERS + p], a);  // the four arrays are contiguous
     }
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64), b += __shfl_down(b, off, 64);
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&P.counters->sum_score[p], a);
-      atomicAdd(&P.counters->sum_reward[p], b);
-    }
-  }
   // order of SkCounters' leading fields: steps, episodes, illegal, resets, sum_len, reshuffles, iters, waits
   const int dst[7] = {0, 1, 2, 3, 4, 5, 7};
   for (int k = 0; k < 7; k++) {

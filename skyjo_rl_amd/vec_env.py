@@ -20,7 +20,8 @@ import numpy as np
 
 from . import _lib
 
-Obs = collections.namedtuple("Obs", "observations action_mask agent phase done status episode_steps")
+Obs = collections.namedtuple("Obs", "observations action_mask agent phase done status episode_steps action",
+                             defaults=(None,))
 
 
 def split_records_np(rec, obs_dim):
@@ -30,10 +31,34 @@ def split_records_np(rec, obs_dim):
     i8 = rec.view(np.int8)
     steps = rec[..., dp + 30].astype(np.uint16) | (rec[..., dp + 31].astype(np.uint16) << 8)
     return Obs(i8[..., :obs_dim], i8[..., dp:dp + 26], rec[..., dp + 26], rec[..., dp + 27], rec[..., dp + 28],
-               rec[..., dp + 29], steps)
+               rec[..., dp + 29], steps, i8[..., obs_dim])
+
+
+class _Snapshot:
+    def __init__(self, L, p):
+        self._L, self._p = L, p
+
+    @property
+    def nbytes(self):
+        n = C.c_size_t()
+        _lib.check(self._L.skyjo_vec_snapshot_bytes(self._p, C.byref(n)))
+        return int(n.value)
+
+    def close(self):
+        if self._p is not None and self._p.value:
+            self._L.skyjo_vec_snapshot_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class SkyjoVecEnv:
+    ACTION_SKIP = _lib.ACTION_SKIP
+
     def __init__(self, num_envs, num_players=3, score_penalty=2.0, observe_other_player_indirect=True,
                  mean_reward=1.0, reward_refunded=0.001, device=0, rng_mode=_lib.RNG_MT19937, auto_reset=True,
                  game_id0=0, illegal_reward=-1.0):
@@ -92,7 +117,7 @@ class SkyjoVecEnv:
         i8 = records.view(torch.int8)
         steps = records[..., dp + 30].to(torch.int32) | (records[..., dp + 31].to(torch.int32) << 8)
         return Obs(i8[..., :self.obs_dim], i8[..., dp:dp + 26], records[..., dp + 26], records[..., dp + 27],
-                   records[..., dp + 28], records[..., dp + 29], steps)
+                   records[..., dp + 28], records[..., dp + 29], steps, i8[..., self.obs_dim])
 
     # ------------------------------------------------------------------ device style API
     def seed(self, seeds=None, base_seed=0):
@@ -103,6 +128,11 @@ class SkyjoVecEnv:
             assert seeds.shape == (self.num_envs,)
             ptr = seeds.ctypes.data_as(C.c_void_p)
         _lib.check(self._L.skyjo_vec_seed(self._h, ptr, int(base_seed), None))
+        _lib.check(self._L.skyjo_dev_sync(None))
+
+    def seed_one(self, game, value):
+        """SkyjoGame.set_seed(value) (skyjo.py:84-88) for ONE game of the batch; the others are untouched."""
+        _lib.check(self._L.skyjo_vec_seed_one(self._h, int(game), int(value), None))
         _lib.check(self._L.skyjo_dev_sync(None))
 
     def reset(self, mask=None, out=None):
@@ -230,15 +260,30 @@ class SkyjoVecEnv:
         N = self.num_players
         return dict(steps=c.steps, episodes=c.episodes, illegal=c.illegal, resets=c.resets, sum_len=c.sum_len,
                     reshuffles=c.reshuffles, iters=c.iters, waits=c.waits,
-                    sum_score=np.array(c.sum_score[:N]), sum_reward=np.array(c.sum_reward[:N]))
+                    sum_score=np.array(c.sum_score[:N]), sum_reward=np.array(c.sum_reward[:N]),
+                    sum_reward_sq=np.array(c.sum_reward_sq[:N]), sum_refunded=np.array(c.sum_refunded[:N]))
 
     def profile(self, enable):
         """Collect-and-clear HIP-event timings of the kernels launched since the last call (bench roofline leg)."""
-        sm, dm = C.c_double(), C.c_double()
-        sl, dl = C.c_int64(), C.c_int64()
-        _lib.check(self._L.skyjo_vec_profile(self._h, int(enable), C.byref(sm), C.byref(sl), C.byref(dm),
-                                             C.byref(dl)))
-        return dict(step_ms=sm.value, step_launches=sl.value, deal_ms=dm.value, deal_launches=dl.value)
+        K = len(_lib.PROF_KERNELS)
+        ms, n = (C.c_double * K)(), (C.c_int64 * K)()
+        _lib.check(self._L.skyjo_vec_profile(self._h, int(enable), ms, n))
+        out = {}
+        for k, name in enumerate(_lib.PROF_KERNELS):
+            out[name + "_ms"], out[name + "_launches"] = ms[k], n[k]
+        out.update(step_ms=ms[0], step_launches=n[0], deal_ms=ms[2], deal_launches=n[2])
+        return out
+
+    # ------------------------------------------------------------------ snapshot / restore (SURVEY 8f.4)
+    def snapshot(self):
+        """Device-resident copy of the whole engine (games, banks, RNG streams and positions, statistics, policy
+        counter).  ``restore(snap)`` makes every later call repeat what followed the snapshot."""
+        sp = C.c_void_p()
+        _lib.check(self._L.skyjo_vec_snapshot_create(self._h, C.byref(sp), None))
+        return _Snapshot(self._L, sp)
+
+    def restore(self, snap):
+        _lib.check(self._L.skyjo_vec_snapshot_restore(self._h, snap._p, None))
 
     def set_deal_interval(self, n):
         _lib.check(self._L.skyjo_vec_set_option(self._h, 1, int(n)))
