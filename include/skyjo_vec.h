@@ -216,8 +216,9 @@ int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
  * place (slow path, same result, counted in skyjo_vec_counters.waits). */
 #define SKYJO_OPT_DEAL_INTERVAL 1
 /* SKYJO_OPT_OVERLAP: 1 = the dealing kernel runs on a stream of its own beside the step kernels that follow it
- * (its episodes are published one dealing cycle later), 0 = it runs in line on the caller's stream (default;
- * environment override SKYJO_OVERLAP).  Results do not depend on this setting. */
+ * (its episodes are published one dealing cycle later), 0 = it runs in line on the caller's stream.  Default: 1 when
+ * the batch leaves SIMDs idle (at most 640 tiles of 64 games), 0 on a full chip; environment override SKYJO_OVERLAP.
+ * Results do not depend on this setting. */
 #define SKYJO_OPT_OVERLAP 2
 int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value);
 int skyjo_vec_get_option(const skyjo_vec *h, int option, int64_t *value_out);

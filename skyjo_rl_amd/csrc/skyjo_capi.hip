@@ -187,7 +187,7 @@ int start_deals(skyjo_vec *h, hipStream_t s) {
   if ((rc = prof_events(h, 2, &e0, &e1))) return rc;
   // fixed player counts deal from a 150-word strip per lane (one card per dword); the generic kernel needs the tile + ring
   const int inl = h->overlap ? 0 : 1;  // in line: k_deal publishes its own episodes, no k_publish launch
-  const uint32_t lds_compact = SK_NCARDS * 256, lds_generic = (uint32_t)(h->lds_tile + 16384);
+  const uint32_t lds_compact = SK_TILE * SK_DECK_STRIDE, lds_generic = (uint32_t)(h->lds_tile + 16384);
   switch (h->P.L.N) {
     case 2: hipExtLaunchKernelGGL(k_deal<2>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel, inl); break;
     case 3: hipExtLaunchKernelGGL(k_deal<3>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel, inl); break;
@@ -307,7 +307,9 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     skyjo_vec_destroy(h);
     return rc;
   }
-  if (hipStreamCreateWithFlags(&h->deal_stream, hipStreamNonBlocking) != hipSuccess ||
+  int prio_least = 0, prio_greatest = 0;  // the dealing kernel fills what the step kernel leaves idle: lowest priority
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (hipStreamCreateWithPriority(&h->deal_stream, hipStreamNonBlocking, prio_least) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_scan, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_dealt, hipEventDisableTiming) != hipSuccess) {
     skyjo_vec_destroy(h);
@@ -324,7 +326,11 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     P.health_host = (volatile uint32_t *)dp;
   }
   h->deal_every_iters = h->interval_default = deal_interval_default(cfg->num_players);
-  h->overlap = false;  // SKYJO_OPT_OVERLAP / SKYJO_OVERLAP=1 switch the second stream on
+  // The dealing kernel runs beside the step kernel (own stream) when the batch leaves SIMDs free: up to 640 tiles of
+  // the 1024 one-wavefront-per-SIMD slots (32 768 three-player games: 14.4 vs 11.7 x 10^9 steps/s).  On a full chip
+  // the two kernels compete for the same vector ALUs and sharing buys 1 % (65 536 games: k_step 155 -> 212 us with
+  // k_deal beside it), so there it runs in line.  SKYJO_OPT_OVERLAP / SKYJO_OVERLAP override.
+  h->overlap = P.tiles <= 640;
   if (const char *e = getenv("SKYJO_OVERLAP")) h->overlap = atoi(e) != 0;
   if (const char *e = getenv("SKYJO_DEAL_INTERVAL")) {
     const int v = atoi(e);

@@ -975,10 +975,14 @@ __device__ __forceinline__ void spare_issue(const SkParams &P, uint8_t *lp, uint
   r.dc = P.deals_consumed[g];
   const uint32_t voff = (uint32_t)((((size_t)r.head * P.tiles + tile) * P.L.chunks * SK_TILE + lane) * 16);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the old record has returned
+#ifndef SK_EXP_NO_DMA
   dma_record<false>((const uint8_t *)P.spare, voff, lds_tile, P.L.chunks);
+#endif
 }
 __device__ __forceinline__ bool spare_commit(const SkParams &P, uint8_t *lp, int g, const SpareRegs &r) {
+#ifndef SK_EXP_NO_DRAIN
   sk_vm_drain();
+#endif
   if (!r.ready) return false;
   P.spare_ready[(size_t)r.head * (size_t)P.tiles * SK_TILE + g] = 0;  // k_scan finds the banks that are not full
   bank_advance(P, lp, g, r.head, r.dc);
@@ -1020,6 +1024,9 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   uint8_t *ap = stg + (INDIRECT ? 4096 : SK_TILE * (P.L.rec_bytes + 16));
   if (lane < SK_ACC_KINDS * P.L.N) ACC(lane) = 0.0;
   STAMP_DECL;
+#ifdef SK_STEP_PRIO
+  __builtin_amdgcn_s_setprio(SK_STEP_PRIO);  // ahead of a dealing wavefront that shares the SIMD
+#endif
   // the tile comes in by LDS-DMA as well (non-temporal: it is read once per launch)
   dma_record<true>((const uint8_t *)P.state, (uint32_t)((((size_t)tile * P.L.chunks) * SK_TILE + lane) * 16), lds_tile, P.L.chunks);
   sk_vm_drain();
@@ -1393,10 +1400,14 @@ struct PhiloxChunkStream {  // same output sequence as PhiloxStream (block b -> 
   }
 };
 
-// The lane's deck: card k is the dword at LDS byte address  dk + (k << 8)  (one card per dword: a position is an
-// address, no byte arithmetic; 150 x 256 B = 37.5 KB of LDS per wavefront, which the 2-3 dealing wavefronts per
-// CU can afford).
-#define DK_AT(addr) (*(uint32_t *)((uint8_t *)lds_raw_base + (addr)))
+// The lane's deck: card k is the BYTE at LDS address  dk + k,  dk = lane * SK_DECK_STRIDE  (a position is still an
+// address: one add).  A stride of 39 dwords spreads the lanes' equal positions over all banks; data-dependent
+// positions of different lanes collide two- or three-way now and then, which the LDS unit absorbs - what the 9.75 KB
+// per wavefront buy (37.5 KB with one card per dword) is room for the dealing wavefronts BESIDE the step kernel's
+// four per CU, so that a dealing run can hide behind the step launches that follow it.
+#define SK_DECK_STRIDE 156
+#define DK_AT(addr) (*((uint8_t *)lds_raw_base + (addr)))
+#define DK_AT32(addr) (*(uint32_t *)((uint8_t *)lds_raw_base + (addr)))
 
 // Legacy RandomState.shuffle (for i = n-1 .. 1: j = rk_interval(i); swap(a[i], a[j])) of the whole deck and then
 // of the rest behind the 12 NP dealt cards (skyjo.py:76-82 and :68-70,:127-138), as ONE lane-private walk: a lane
@@ -1422,13 +1433,13 @@ __device__ __forceinline__ void deck_batch(Rng &r, const int s, uint32_t *lds_ra
     const uint32_t v = r.R[s + k] & w.mask;
     const bool acc = PRO ? (v < w.n && s + k >= r.pos) : (v < w.n);
     pI[k] = w.pcur;
-    pJ[k] = acc ? w.pb + (v << 8) : w.pcur;
+    pJ[k] = acc ? w.pb + v : w.pcur;
     const uint32_t d = acc ? 0xffffffffu : 0u;
     const uint32_t n2 = w.n + d;
     const bool t = n2 == 1u;  // this shuffle is complete (i reached 0): on to the rest, or done
     w.n = t ? w.nxt_n : n2;
-    w.pcur = t ? dk + ((SK_NCARDS - 1) << 8) : w.pcur + (d << 8);
-    w.pb = t ? dk + ((12 * NP) << 8) : w.pb;
+    w.pcur = t ? dk + (SK_NCARDS - 1) : w.pcur + d;
+    w.pb = t ? dk + 12 * NP : w.pb;
     r.pos = t ? s + k + 1 : r.pos;  // (a lane that is still shuffling after the block gets pos = 16 from the caller)
     w.mask = 0xffffffffu >> __builtin_clz(w.n - 1u);  // (n - 1 is never 0)
   }
@@ -1447,7 +1458,7 @@ __device__ __forceinline__ void deck_batch(Rng &r, const int s, uint32_t *lds_ra
       cJ[k] = pJ[m] == pJ[k] ? cI[m] : cJ[k];
     }
 #pragma unroll
-  for (int k = 0; k < BS; k++) DK_AT(pI[k]) = cJ[k], DK_AT(pJ[k]) = cI[k];
+  for (int k = 0; k < BS; k++) DK_AT(pI[k]) = (uint8_t)cJ[k], DK_AT(pJ[k]) = (uint8_t)cI[k];
 }
 
 // _reset_card_mask (skyjo.py:96-103): choice(12, 2, replace=False) == permutation(12)[:2] per player, i.e. a full
@@ -1494,13 +1505,19 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_ra
                                              uint4 *dst) {
   constexpr int R = SK_NCARDS - 12 * NP;
   const SkLayout L = sk_make_layout(NP, P.L.indirect);
-  const uint32_t dk = (uint32_t)lane * 4u;  // LDS address of the lane's card 0
-#define DKW(k) DK_AT(dk + ((k) << 8))
+  const uint32_t dk = (uint32_t)lane * SK_DECK_STRIDE;  // LDS address of the lane's card 0
+#define DKW(k) ((uint32_t)DK_AT(dk + (k)))
 #pragma unroll
-  for (int k = 0; k < SK_NCARDS; k++) DKW(k) = (uint32_t)((-2 + k / 10) & 0xff);  // _new_drawpile (skyjo.py:76-82)
+  for (int d = 0; d < (SK_NCARDS + 3) / 4; d++) {  // _new_drawpile (skyjo.py:76-82), four cards per write
+    uint32_t w4 = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (4 * d + j < SK_NCARDS) w4 |= (uint32_t)((-2 + (4 * d + j) / 10) & 0xff) << (8 * j);
+    DK_AT32(dk + 4 * d) = w4;
+  }
   {
     DeckWalk w;
-    w.pb = dk, w.pcur = dk + ((SK_NCARDS - 1) << 8), w.n = SK_NCARDS, w.nxt_n = R, w.mask = 0xffu;
+    w.pb = dk, w.pcur = dk + (SK_NCARDS - 1), w.n = SK_NCARDS, w.nxt_n = R, w.mask = 0xffu;
     if (r.pos < 16) {
 #define SK_CALL(s) deck_batch<true, NP>(r, s, lds_raw_base, dk, w);
       SK_DECK_BATCHES(SK_CALL)
@@ -1540,12 +1557,9 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_ra
 #pragma unroll
   for (int w = 0; w < 20 * 4; w++) rec[w] = 0;
   auto setb = [&](int off, uint32_t val) { rec[off >> 2] |= (val & 0xffu) << ((off & 3) * 8); };
-  auto pack4 = [&](int k) {  // deck cards k .. k+3 as four bytes (cards beyond the deck read as 0)
-    uint32_t w = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (k + j < SK_NCARDS) w |= DKW(k + j) << (8 * j);
-    return w;
+  auto pack4 = [&](int k) {  // deck cards k .. k+3 as four bytes: one aligned word of the lane's deck (cards beyond the deck read as 0)
+    const uint32_t w = DK_AT32(dk + k);
+    return k + 4 <= SK_NCARDS ? w : (w & (0xffffffffu >> (8 * (k + 4 - SK_NCARDS))));
   };
   const int last = (int)(int8_t)DKW(SK_NCARDS - 1);
   int best = 0, bs = -1000, ms = 1000;
