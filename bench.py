@@ -3,21 +3,33 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A "step" is one lockstep pass of the hot path over the whole batch: every live game applies one
-action chosen by the on-device random admissible policy (state transition + observation / action
-mask build, record and action written to HBM), finished games take their next deal.  The workload
-is BASELINE.json configs[2]: 65 536 parallel 3-player games per GPU, DEFAULT_CONFIG (indirect
-observation, D = 31), game g seeded base + g, numpy-legacy MT19937 deals (bit-identical to the
-reference).  `value` = env-steps (applied actions, counted on device) of all ranks / max-over-ranks
-wall time, inputs resident in HBM.  One JSON line on stdout (rank 0).
+A bench "step" is ONE FUSED LAUNCH of the hot path over the whole batch: `iterations_per_launch` (80)
+lockstep iterations - in each of them every live game applies one action chosen by the on-device
+random admissible policy (state transition + observation / action-mask build, the 64-byte record
+with the applied action written to HBM) and finished games take their next deal - plus the dealing
+run (k_scan + k_deal) that the engine starts once per 80 iterations.  So `--steps 20 --warmup 5` are
+1 600 timed lockstep iterations after 400 untimed ones (about 15 episodes per game inside the timed
+region); the defaults are 250 / 25 launches.  The workload is BASELINE.json configs[2]: 65 536
+parallel 3-player games per GPU, DEFAULT_CONFIG (indirect observation, D = 31), game g seeded
+base + g, numpy-legacy MT19937 deals (bit-identical to the reference).  `value` = env-steps (applied
+actions, counted on device) of all ranks / max-over-ranks wall time, inputs resident in HBM.  One
+JSON line on stdout (rank 0).
+
+`--gpus N` (N > 1) without a torchrun environment starts the N ranks itself: a fresh
+`python -m torch.distributed.run` child, started before this process touches the GPU.
 
 Extra objects on the same line:
-  roofline      dominant kernel (k_step, fused rollout) timed with HIP events on its launch stream
-  cpu_baseline  the CPU oracle (oracle/, a port of the reference's algorithm) timed on host cores
+  roofline       dominant kernel (k_step, fused rollout) timed with HIP events on its launch stream
+  roofline_path  the whole path (k_step + k_scan + k_deal [+ k_publish] per dealing cycle): kernel-time sum
+                 from the same events, and the wall time of the timed region
+  episode_stats  what the ranks all-gather (RCCL): per-seat reward / score statistics
+  cpu_baseline   the CPU oracle (oracle/, a port of the reference's algorithm) timed on host cores
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,11 +42,11 @@ CHUNK = int(os.environ.get("SKYJO_BENCH_CHUNK", "80"))  # lockstep iterations pe
                                                          # 80 = the engine's dealing interval for 3 and more players)
 
 
-def algorithmic_bytes_per_launch(B, N, D, iters, actions=True):
-    """packed state S(N) = 24N + 150 + 16 read once and written once per launch,
-    plus per env-step the record the path must emit: D obs + 26 mask + 2 (agent, done) (+4 action)."""
+def algorithmic_bytes_per_launch(B, N, D, iters, records=True):
+    """packed state S(N) = 24N + 150 + 16 read once and written once per launch, plus per env-step the
+    record the path must emit: D obs + 26 mask + 2 (agent, done) + 1 (the action as int8, byte D of the record)."""
     S = 24 * N + 150 + 16
-    per_step = D + 26 + 2 + (4 if actions else 0)
+    per_step = (D + 26 + 2 + 1) if records else 0
     return B * (2 * S + iters * per_step)
 
 
@@ -70,53 +82,75 @@ def cpu_baseline(num_players, seconds=12.0):
                       f"oracle/skyjo_oracle.c with OpenMP over games, same on-device-policy restatement"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a fresh child (this process has not touched the
+    GPU and never will), pass its one JSON line through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)   # 57 ms of GPU time at 2.8 us per lockstep iteration: short enough to
-    ap.add_argument("--warmup", type=int, default=2000)   # finish at once, long enough that the first launches after the barrier do not show
+    ap.add_argument("--steps", type=int, default=250, help="timed fused launches of 80 lockstep iterations each")
+    ap.add_argument("--warmup", type=int, default=25, help="untimed launches before them")
     ap.add_argument("--num-envs", type=int, default=65536, help="games per GPU")
     ap.add_argument("--num-players", type=int, default=3)
     ap.add_argument("--rng", choices=["mt19937", "philox"], default="mt19937")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-records", action="store_true", help="do not write records/actions (not the headline)")
+    ap.add_argument("--no-records", action="store_true", help="do not write records (not the headline)")
+    ap.add_argument("--actions-array", action="store_true", help="also write the int32 action array (the action is byte D of every record anyway)")
     ap.add_argument("--direct-obs", action="store_true", help="observe_other_player_indirect=False: D = 19 + 12 N (not the headline)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import torch
     import torch.distributed as dist
 
-    from skyjo_rl_amd import RNG_MT19937, RNG_PHILOX, SkyjoVecEnv
+    from skyjo_rl_amd import RNG_MT19937, RNG_PHILOX
+    from skyjo_rl_amd.distributed import gather_stats, make_sharded_env
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    assert ndev > 0, "bench.py needs a GPU"
+    shared_gpu = world > ndev  # rehearsal on a box with fewer GPUs than ranks: ranks share cards, gloo carries the record
+    device = local_rank % ndev
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    torch.cuda.set_device(device)
+    dev = torch.device("cuda", device)
 
     B, N = args.num_envs, args.num_players
-    global CHUNK
-    if N < 3:
-        CHUNK = min(CHUNK, 64)  # the engine deals every 64 iterations below three players (shorter episodes)
-    eng = SkyjoVecEnv(B, num_players=N, score_penalty=2.0, observe_other_player_indirect=not args.direct_obs, mean_reward=1.0,
-                      reward_refunded=0.001, device=local_rank,
-                      rng_mode=RNG_MT19937 if args.rng == "mt19937" else RNG_PHILOX, auto_reset=True,
-                      game_id0=rank * B)  # shards by global game id: results do not depend on the GPU count
+    # shards by global game id (rank r owns games r*B .. (r+1)*B - 1): results do not depend on the GPU count
+    eng = make_sharded_env(world * B, rank, world, num_players=N, score_penalty=2.0, observe_other_player_indirect=not args.direct_obs,
+                           mean_reward=1.0, reward_refunded=0.001, device=device,
+                           rng_mode=RNG_MT19937 if args.rng == "mt19937" else RNG_PHILOX, auto_reset=True)
+    assert eng.num_envs == B and eng.game_id0 == rank * B
     eng.seed(None, 0)
+    global CHUNK
+    CHUNK = min(CHUNK, eng.deal_interval())  # one launch per dealing cycle (64 iterations below three players / beside-the-step dealing)
     D = eng.obs_dim
     record = not args.no_records
     rec = eng.new_records(CHUNK) if record else None           # [CHUNK, B, 64] ring reused by every launch
-    act = torch.empty((CHUNK, B), dtype=torch.int32, device=dev) if record else None
+    act = torch.empty((CHUNK, B), dtype=torch.int32, device=dev) if args.actions_array else None
 
-    def run(iters):
-        done = 0
-        while done < iters:
-            n = min(CHUNK, iters - done)
-            eng.rollout(n, policy_seed=1, records=rec[:n] if record else None, actions=act[:n] if record else None)
-            done += n
+    def run(launches):
+        for _ in range(launches):
+            eng.rollout(CHUNK, policy_seed=1, records=rec, actions=act)
 
     def barrier():
         torch.cuda.synchronize()
@@ -127,6 +161,7 @@ def main():
     run(args.warmup)
     barrier()
     c0 = eng.counters()
+    eng.reset_counters()
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
@@ -134,35 +169,41 @@ def main():
     dt = time.perf_counter() - t0
     c1 = eng.counters()
 
-    # the one collective of the path: per-rank episode statistics, all-gathered over RCCL
-    stats = torch.tensor([c1["steps"] - c0["steps"], c1["episodes"] - c0["episodes"], c1["sum_len"] - c0["sum_len"],
-                          c1["resets"] - c0["resets"], c1["waits"] - c0["waits"], c1["illegal"] - c0["illegal"], dt],
-                         dtype=torch.float64, device=dev)
+    # the one collective of the path: per-rank episode statistics (counts + per-seat reward / score sums), all-gathered
+    # over RCCL (device tensors; gloo when ranks share a card)
+    c1["wall"] = dt
+    per_rank, tot = gather_stats(c1, N, device=dev)
     if world > 1:
-        gathered = [torch.empty_like(stats) for _ in range(world)]
-        dist.all_gather(gathered, stats)
-        allstats = torch.stack(gathered).cpu()
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_max = float(t.item())
     else:
-        allstats = stats.cpu().unsqueeze(0)
-    steps_total = float(allstats[:, 0].sum())
-    t_max = float(allstats[:, 6].max())
+        t_max = dt
+    steps_total = float(tot["steps"])
+    episodes = float(tot["episodes"])
+    # every rank must have been in steady state: games ended and were re-dealt inside the timed region, nobody dealt in place
+    assert c1["episodes"] > 0 and c1["resets"] > 0, "no episode ended inside the timed region: --steps too small to mean anything"
+    assert c1["waits"] == 0, f"{c1['waits']} deals were made on the in-kernel slow path (bank ran dry)"
+    assert c1["iters"] == args.steps * CHUNK
 
-    # roofline leg: the same launches again, each k_step launch carrying a HIP event pair that receives the
-    # kernel's begin / end timestamps on its launch stream (comparable with rocprofv3's kernel trace, profiles/)
+    # roofline leg: the same launches again, every kernel carrying a HIP event pair that receives its begin / end
+    # timestamps on its launch stream (comparable with rocprofv3's kernel trace, profiles/)
     eng.profile(1)
-    run(32 * CHUNK)
+    run(32)
     prof = eng.profile(0)
     full = prof["step_launches"]
     avg_ms = prof["step_ms"] / max(full, 1)
-    alg = algorithmic_bytes_per_launch(B, N, D, CHUNK, actions=record)
+    alg = algorithmic_bytes_per_launch(B, N, D, CHUNK, records=record) + (4 * B * CHUNK if act is not None else 0)
     achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
-    if os.path.exists(tpath) and B == 65536 and N == 3 and record and CHUNK == 80:  # (the PMC passes ran this very launch shape)
+    tpath = os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")
+    if os.path.exists(tpath) and B == 65536 and N == 3 and record and act is None and CHUNK == 80:  # (the PMC passes ran this very launch shape)
         traffic = json.load(open(tpath)).get("k_step_bytes_per_launch")
+    kernel_ms = {k: prof[k + "_ms"] / 32.0 for k in ("k_step", "k_scan", "k_deal", "k_publish")}  # per bench step (= per dealing cycle)
+    path_ms = sum(kernel_ms.values())
+    wall_ms = 1e3 * t_max / args.steps
 
     if rank == 0:
-        episodes = float(allstats[:, 1].sum())
         out = {
             "metric": "env-steps/sec (whole node) at 65 536 parallel 3-player games",
             "value": steps_total / t_max,
@@ -170,25 +211,44 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * t_max / args.steps,
+            "ms_per_step": wall_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "int8",
             "data": "synthetic",
             "config": {"workload": f"{B} parallel {N}-player games per GPU, random admissible policy on device, "
-                                   f"{'direct' if args.direct_obs else 'DEFAULT_CONFIG (indirect'} obs D={D}{'' if args.direct_obs else ')'}, auto-reset, records+actions written every step"
+                                   f"{'direct' if args.direct_obs else 'DEFAULT_CONFIG (indirect'} obs D={D}{'' if args.direct_obs else ')'}, auto-reset, "
+                                   f"record (obs + mask + applied action) written every step; one bench step = one fused launch of {CHUNK} lockstep iterations + its dealing run"
                                    if record else f"{B} x {N}-player games per GPU, no records",
                        "games_per_gpu": B, "num_players": N, "rng_mode": args.rng,
-                       "iterations_per_launch": CHUNK, "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
-            "mean_episode_len": float(allstats[:, 2].sum()) / max(episodes, 1.0),
+                       "iterations_per_step": CHUNK, "timed_iterations": args.steps * CHUNK, "warmup_iterations": args.warmup * CHUNK,
+                       "dealing": "beside k_step (own stream)" if eng.overlap() else "in line",
+                       "shared_gpu_rehearsal": shared_gpu,
+                       "parallelism": f"games sharded over {world} GPU(s) by global game id, no data-path collective; one all-gather of the statistics record"},
+            "ms_per_iteration": wall_ms / CHUNK,
+            "mean_episode_len": float(tot["mean_episode_len"]),
             "episodes": episodes,
-            "waits": float(allstats[:, 4].sum()),
+            "waits": float(tot["waits"]),
+            "episode_stats": {"record_doubles_per_rank": int(per_rank.shape[1]), "ranks": int(per_rank.shape[0]),
+                              "mean_reward_per_seat": [float(x) for x in tot["mean_reward"]],
+                              "std_reward_per_seat": [float(x) for x in tot["std_reward"]],
+                              "mean_score_per_seat": [float(x) for x in tot["mean_score"]],
+                              "refunded_per_episode": float(tot["sum_refunded"].sum() / max(episodes, 1.0))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step<indirect,policy>", "avg_launch_ms": avg_ms, "launches_timed": full,
+                         "kernel": "k_step<indirect,policy,3>" if N == 3 and record else "k_step", "avg_launch_ms": avg_ms, "launches_timed": full,
                          "algorithmic_bytes_per_launch": alg,
                          "deal_kernel_avg_ms": prof["deal_ms"] / max(prof["deal_launches"], 1)},
+            "roofline_path": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                              "kernel_ms_per_step": kernel_ms, "kernel_ms_sum": path_ms,
+                              "achieved_kernel_time": alg / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0,
+                              "frac_kernel_time": alg / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if path_ms > 0 else 0.0,
+                              "wall_ms_per_step": wall_ms,
+                              "achieved_wall": alg / (wall_ms * 1e-3) / 1e9,
+                              "frac_wall": alg / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "note": "algorithmic bytes of one k_step launch over the time of one whole dealing cycle; with the dealing kernel "
+                                      "on its own stream the kernel times overlap and only the wall figure is a path time"},
         }
         if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: a reported baseline, not part of the scaling runs)
             out["cpu_baseline"] = cpu_baseline(N)

@@ -415,6 +415,14 @@ void sko_vec_seed(sko_vec *v, const uint64_t *seeds, uint64_t base) {
   }
 }
 
+/* set_seed(value) for one game of the batch (skyjo.py:84-88); the others are untouched */
+void sko_vec_seed_one(sko_vec *v, int i, uint64_t value) {
+  sko_set_seed(&v->games[i], value);
+  vec_new_episode(v, i);
+  v->status[i] = SKO_ST_RESET;
+  v->resets++; /* one deal consumed, like a reset (the whole-batch seed starts the counters afresh instead) */
+}
+
 void sko_vec_reset(sko_vec *v, const uint8_t *mask) {
   for (int i = 0; i < v->num_envs; i++)
     if (!mask || mask[i]) {
@@ -430,6 +438,7 @@ static void vec_step_one(sko_vec *v, int i, int action, uint64_t *steps, uint64_
   sko_game *g = &v->games[i];
   const int N = v->num_players;
   double *rew = &v->rewards[(size_t)i * N];
+  if (action == SKO_ACTION_SKIP) return; /* the game is left exactly as it is (include/skyjo_vec.h SKYJO_ACTION_SKIP) */
   if (v->done[i]) {
     if (v->auto_reset) {
       sko_reset(g);

@@ -42,6 +42,7 @@ extern "C" {
 #define SKO_ST_ILLEGAL 1
 #define SKO_ST_NOOP_DONE 2
 #define SKO_ST_RESET 3
+#define SKO_ACTION_SKIP (-1000) /* sko_vec_step: leave this game as it is */
 
 #define SKO_RNG_MT19937 0 /* numpy legacy stream: bit-identical to the reference */
 #define SKO_RNG_PHILOX 1  /* counter-based Philox4x32-10 sessions (build's own definition) */
@@ -126,6 +127,7 @@ sko_vec *sko_vec_create(int num_envs, int num_players, double score_penalty, int
                         double reward_refunded, int rng_mode, int auto_reset, uint64_t game_id0);
 void sko_vec_destroy(sko_vec *v);
 void sko_vec_seed(sko_vec *v, const uint64_t *seeds, uint64_t base); /* per game set_seed(seed) */
+void sko_vec_seed_one(sko_vec *v, int i, uint64_t value);
 void sko_vec_reset(sko_vec *v, const uint8_t *mask);
 void sko_vec_step(sko_vec *v, const int32_t *actions, int threads);
 void sko_vec_observe(const sko_vec *v, const int32_t *players, int8_t *obs, int8_t *mask, uint8_t *agent,

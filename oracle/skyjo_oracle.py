@@ -14,6 +14,7 @@ _SO = os.path.join(_HERE, "_build", "libskyjo_oracle.so")
 
 ST_OK, ST_ILLEGAL, ST_NOOP_DONE, ST_RESET = 0, 1, 2, 3
 RNG_MT19937, RNG_PHILOX = 0, 1
+ACTION_SKIP = -1000
 MAXP = 12
 
 
@@ -69,6 +70,7 @@ def lib():
         L.sko_init.argtypes = [C.POINTER(Game), C.c_int, C.c_double, C.c_int, C.c_int]
         L.sko_set_seed.argtypes = [C.POINTER(Game), C.c_uint64]
         L.sko_vec_seed.argtypes = [C.POINTER(Vec), C.c_void_p, C.c_uint64]
+        L.sko_vec_seed_one.argtypes = [C.POINTER(Vec), C.c_int, C.c_uint64]
         L.sko_vec_reset.argtypes = [C.POINTER(Vec), C.c_void_p]
         L.sko_vec_step.argtypes = [C.POINTER(Vec), C.c_void_p, C.c_int]
         L.sko_vec_observe.argtypes = [C.POINTER(Vec), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -181,6 +183,20 @@ class OracleVec:
     def seed(self, seeds=None, base=0):
         s = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint64)
         self.L.sko_vec_seed(self.v, _p(s), int(base))
+
+    def seed_one(self, game, value):
+        self.L.sko_vec_seed_one(self.v, int(game), int(value))
+
+    def set_state(self, game, cards, masked, draw, disc, hand=15, player=0, phase=0):
+        """Fixture injection into one game of the batch (sko_set_state)."""
+        N = self.num_players
+        c = np.ascontiguousarray(np.asarray(cards, dtype=np.int8).reshape(N, 12))
+        m = np.ascontiguousarray(np.asarray(masked, dtype=np.int8).reshape(N, 12))
+        d = np.ascontiguousarray(draw, dtype=np.int8).ravel()
+        s = np.ascontiguousarray(disc, dtype=np.int8).ravel()
+        self.L.sko_set_state(C.byref(self.v.contents.games[game]), _p(c), _p(m), _p(d), len(d), _p(s), len(s), int(hand),
+                             int(player), int(phase))
+        self.v.contents.done[game] = 0
 
     def reset(self, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)

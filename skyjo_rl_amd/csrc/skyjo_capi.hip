@@ -50,7 +50,11 @@ constexpr int kMaxRolloutChunk = 128;  // lockstep iterations per k_step launch 
 // 76 / 105 / 134 steps for 2 / 3 / 4 players) or the banks of SK_BANK episodes drain and finished games deal in
 // place (deal_inline: slow, same result).  Measured at 65 536 three-player games: 64 -> 20.3, 80 -> 21.6,
 // 96 -> 21.9 x 10^9 steps/s, 104 and more drain.
-constexpr int deal_interval_default(int num_players) { return num_players >= 3 ? 80 : 64; }
+// With the dealing kernel on its own stream a run's episodes arrive one interval later, so the interval is a step
+// shorter there (the runs are hidden behind the step kernel anyway).
+constexpr int deal_interval_default(int num_players, bool overlap) {
+  return overlap ? (num_players >= 3 ? 64 : 48) : (num_players >= 3 ? 80 : 64);
+}
 
 }  // namespace
 
@@ -325,13 +329,13 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     h->health_host[0] = h->health_host[1] = 0;
     P.health_host = (volatile uint32_t *)dp;
   }
-  h->deal_every_iters = h->interval_default = deal_interval_default(cfg->num_players);
   // The dealing kernel runs beside the step kernel (own stream) when the batch leaves SIMDs free: up to 640 tiles of
   // the 1024 one-wavefront-per-SIMD slots (32 768 three-player games: 14.4 vs 11.7 x 10^9 steps/s).  On a full chip
   // the two kernels compete for the same vector ALUs and sharing buys 1 % (65 536 games: k_step 155 -> 212 us with
   // k_deal beside it), so there it runs in line.  SKYJO_OPT_OVERLAP / SKYJO_OVERLAP override.
   h->overlap = P.tiles <= 640;
   if (const char *e = getenv("SKYJO_OVERLAP")) h->overlap = atoi(e) != 0;
+  h->deal_every_iters = h->interval_default = deal_interval_default(cfg->num_players, h->overlap);
   if (const char *e = getenv("SKYJO_DEAL_INTERVAL")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 1024) h->deal_every_iters = v, h->auto_interval = false;
@@ -529,7 +533,9 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
   uint8_t *rec = (uint8_t *)records_out;
   for (int done = 0; done < iters;) {
     int n = iters - done < kMaxRolloutChunk ? iters - done : kMaxRolloutChunk;
-    if (n > h->deal_every_iters) n = h->deal_every_iters;  // (a launch is never longer than the dealing interval in force)
+    // a launch ends where the next dealing run is due, so the cadence does not depend on how the caller slices its calls
+    const int due = h->deal_every_iters - h->pending_iters;
+    if (n > due) n = due > 0 ? due : 1;
     int rc = launch_step(h, s, true, nullptr, rec, actions_out, n, policy_seed);
     if (rc) return rc;
     done += n;
@@ -897,6 +903,8 @@ int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
       if (rc) return rc;
       HIPCHK(hipDeviceSynchronize());
       h->overlap = value != 0;
+      h->interval_default = deal_interval_default(h->P.L.N, h->overlap);
+      if (h->auto_interval) h->deal_every_iters = h->interval_default;
       return SKYJO_OK;
     }
     default:

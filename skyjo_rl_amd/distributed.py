@@ -8,6 +8,7 @@ trajectories do not depend on how many ranks the batch is split over.
 import numpy as np
 
 STAT_FIELDS = ("steps", "episodes", "illegal", "resets", "sum_len", "reshuffles", "waits")
+SEAT_FIELDS = ("sum_score", "sum_reward", "sum_reward_sq", "sum_refunded")  # float64 [num_players] each
 
 
 def shard_range(total_envs, world_size, rank):
@@ -27,9 +28,10 @@ def make_sharded_env(total_envs, rank, world_size, engine_factory=None, **config
 
 
 def stats_record(counters, num_players):
-    """Fixed-size float64 record [len(STAT_FIELDS) + 2 * num_players] of one rank."""
+    """Fixed-size float64 record [len(STAT_FIELDS) + len(SEAT_FIELDS) * num_players] of one rank:
+    {steps, episodes, illegal, resets, sum of episode lengths, ...} + per seat {score, reward, reward^2, refunded} sums."""
     rec = [float(counters.get(k, 0)) for k in STAT_FIELDS]
-    for key in ("sum_score", "sum_reward"):
+    for key in SEAT_FIELDS:
         v = counters.get(key)
         rec += [float(x) for x in (v if v is not None else np.zeros(num_players))][:num_players]
     return rec
@@ -42,6 +44,8 @@ def gather_stats(counters, num_players, device=None):
 
     rec = torch.tensor(stats_record(counters, num_players), dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "gloo":  # (gloo gathers host tensors only; "nccl" = RCCL takes the device tensor as it is)
+            rec = rec.cpu()
         out = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
         dist.all_gather(out, rec)
         allr = torch.stack(out).cpu().numpy()
@@ -50,7 +54,11 @@ def gather_stats(counters, num_players, device=None):
     tot = allr.sum(0)
     totals = {k: tot[i] for i, k in enumerate(STAT_FIELDS)}
     n = len(STAT_FIELDS)
-    totals["sum_score"] = tot[n:n + num_players]
-    totals["sum_reward"] = tot[n + num_players:n + 2 * num_players]
+    for j, key in enumerate(SEAT_FIELDS):
+        totals[key] = tot[n + j * num_players:n + (j + 1) * num_players]
     totals["mean_episode_len"] = totals["sum_len"] / max(totals["episodes"], 1.0)
+    ep = max(totals["episodes"] + totals["illegal"], 1.0)
+    totals["mean_reward"] = totals["sum_reward"] / ep                       # per seat, over finished + illegal episodes
+    totals["std_reward"] = np.sqrt(np.maximum(totals["sum_reward_sq"] / ep - totals["mean_reward"] ** 2, 0.0))
+    totals["mean_score"] = totals["sum_score"] / max(totals["episodes"], 1.0)
     return allr, totals

@@ -11,9 +11,14 @@ for the reference core API (rlskyjo/game/sample_game.py:5-28) run unchanged:
         obs, mask = game.collect_observation(pid)
         game.act(pid, policy_ra(obs, mask))
 
-An *engine* is any object with the host-style methods of ``SkyjoVecEnv`` (seed, reset_host,
-step_host, observe_host, rewards_host, get_state, set_state); tests inject an oracle-backed one
-to check this file without a GPU.
+``SkyjoGame(engine=shared_engine, index=i)`` is a view of game ``i`` of a batched engine: its
+``set_seed`` / ``reset`` / ``act`` touch that one game (``seed_one``, a one-game reset mask, and a
+step in which every other game gets ``ACTION_SKIP``), so single-game code can be pointed at any
+game of a running batch.
+
+An *engine* is any object with the host-style methods of ``SkyjoVecEnv`` (seed, seed_one,
+reset_host, step_host, observe_host, rewards_host, get_state, set_state); tests inject an
+oracle-backed one to check this file without a GPU.
 """
 import math
 import os
@@ -72,6 +77,10 @@ class SkyjoGame(object):
         a[self._i] = value
         return a
 
+    def sync(self):
+        """Re-read this game from the engine (after the engine was stepped or its state injected behind the view's back)."""
+        self._take(self._engine.observe_host())
+
     # ---- reset utils (skyjo.py:52-94) -----------------------------------------------------------
     def reset(self):
         self._take(self._engine.reset_host(self._only_me(1, 0, np.uint8)))
@@ -83,7 +92,7 @@ class SkyjoGame(object):
         if self._engine.num_envs == 1:
             self._engine.seed(np.array([value], dtype=np.uint64))
         else:
-            raise NotImplementedError("re-seeding one game of a shared engine: seed the engine instead")
+            self._engine.seed_one(self._i, value)  # the other games of a shared engine keep their streams
         self._take(self._engine.observe_host())
 
     # ---- observation (skyjo.py:148-199) -----------------------------------------------------------
@@ -114,9 +123,7 @@ class SkyjoGame(object):
             assert self._rec["action_mask"][action_int] == 1, (
                 f"illegal action {self.render_action_explainer(action_int)}."
                 f"card is already revealed: {self.players_masked[player_id]}")
-        acts = self._only_me(int(action_int), 24, np.int32)
-        if self._engine.num_envs > 1:
-            raise NotImplementedError("stepping one game of a shared engine")
+        acts = self._only_me(int(action_int), self._engine.ACTION_SKIP, np.int32)  # the other games stay as they are
         self._take(self._engine.step_host(acts))
         assert self._rec["status"] != ST_ILLEGAL
         return self._rec["done"]
@@ -156,8 +163,15 @@ class SkyjoGame(object):
     @property
     def game_metrics(self):
         s = self._state_now()
+        final = False
+        if s["is_terminated"]:
+            # skyjo.py:477-498 starts from a list of Python floats and adds numpy integers to it: an entry becomes a
+            # numpy float64 as soon as one column of that player counts, and stays a Python float (0.0) otherwise.
+            # The difference shows in render_table()'s "Results: {...}" (repr of the values), so it is kept.
+            counted = [any(len(set(row[3 * c:3 * c + 3])) > 1 for c in range(4)) for row in s["cards"].tolist()]
+            final = [np.float64(x) if k else float(x) for x, k in zip(s["final_score"], counted)]
         return {"num_refunded": [int(x) for x in s["num_refunded"]], "num_placed": [int(x) for x in s["num_placed"]],
-                "final_score": [float(x) for x in s["final_score"]] if s["is_terminated"] else False}
+                "final_score": final}
 
     def get_game_metrics(self):
         return self.game_metrics

@@ -294,6 +294,12 @@ class SkyjoVecEnv:
         _lib.check(self._L.skyjo_vec_get_option(self._h, 1, C.byref(v)))
         return int(v.value)
 
+    def overlap(self):
+        """True when the dealing kernel runs on its own stream beside the step kernels (default below 41 000 games)."""
+        v = C.c_int64()
+        _lib.check(self._L.skyjo_vec_get_option(self._h, 2, C.byref(v)))
+        return bool(v.value)
+
     def set_overlap(self, on):
         """Run the dealing kernel on its own stream beside the step kernels (results do not depend on it)."""
         _lib.check(self._L.skyjo_vec_set_option(self._h, 2, int(bool(on))))

@@ -29,8 +29,16 @@ class OracleEngine:
         ep = np.array([self.v.v.contents.ep_len[i] for i in range(self.num_envs)], dtype=np.uint16)
         return Obs(obs, mask, agent, phase, self.v.dones, self.v.status, ep)
 
+    ACTION_SKIP = so.ACTION_SKIP
+
     def seed(self, seeds=None, base_seed=0):
         self.v.seed(seeds, base_seed)
+
+    def seed_one(self, game, value):
+        self.v.seed_one(game, value)
+
+    def set_state(self, game, cards, masked, draw, disc, hand=15, player=0, phase=0, **_):
+        self.v.set_state(game, cards, masked, draw, disc, hand, player, phase)
 
     def reset_host(self, mask=None):
         self.v.reset(mask)

@@ -302,6 +302,8 @@ def test_dealing_interval_adapts_to_short_episodes():
     cfg = dict(num_players=1, score_penalty=2.0, observe_other_player_indirect=True, mean_reward=1.0,
                reward_refunded=0.001, rng_mode=0, auto_reset=True)
     eng = _engine(B, **cfg)
+    assert eng.overlap() and eng.deal_interval() == 48  # a small batch deals beside the step kernel, one step shorter interval
+    eng.set_overlap(False)
     ora = _oracle_vec(num_envs=B, **cfg)
     eng.seed(None, 5)
     ora.seed(None, 5)

@@ -1,0 +1,184 @@
+"""GPU: multi-GPU shard semantics on one card (BASELINE config 4: 8 x 32 768 games, shard r owns global game ids
+r*32768 ...), the product's statistics gather in two processes, whole-engine snapshot / restore, and the per-handle
+device guard of the C ABI."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = dict(num_players=3, score_penalty=2.0, observe_other_player_indirect=True, mean_reward=1.0, reward_refunded=0.001,
+           rng_mode=0, auto_reset=True)
+
+
+def _engine(*a, **k):
+    from skyjo_rl_amd import SkyjoVecEnv
+    return SkyjoVecEnv(*a, **k)
+
+
+def test_config4_shard_32768_with_game_id0():
+    """Rank 3 of BASELINE config 4: 32 768 games with game_id0 = 3 * 32 768 (the dealing kernel runs beside the step
+    kernel at this size).  A 256-game window of the shard is re-simulated by the oracle from global ids alone."""
+    import torch
+    from oracle import skyjo_oracle as so
+    from skyjo_rl_amd.distributed import make_sharded_env, shard_range
+
+    first, count = shard_range(262144, 8, 3)
+    assert (first, count) == (3 * 32768, 32768)
+    eng = make_sharded_env(262144, 3, 8, **CFG)
+    assert eng.num_envs == count and eng.game_id0 == first
+    eng.seed(None, 0)
+    lo, n = 20000, 256
+    ora = so.OracleVec(num_envs=n, game_id0=first + lo, **CFG)
+    ora.seed(None, 0)
+    K = 80
+    for r in range(5):
+        rec = eng.new_records(K)
+        eng.rollout(K, policy_seed=1, records=rec)
+        oact = ora.rollout(K, 1, record_actions=True)
+        v = eng.split(rec)
+        np.testing.assert_array_equal(v.action[:, lo:lo + n].cpu().numpy(), oact.astype(np.int8), err_msg=f"round {r}")
+        obs, mask, agent, phase = ora.observe()
+        np.testing.assert_array_equal(v.observations[K - 1, lo:lo + n].cpu().numpy(), obs)
+        np.testing.assert_array_equal(v.action_mask[K - 1, lo:lo + n].cpu().numpy(), mask)
+    c = eng.counters()
+    assert c["steps"] + c["resets"] == 5 * K * count and c["waits"] == 0 and c["episodes"] > 2 * count
+    # per-seat statistics of the RCCL record: mean reward over seats == mean_reward + refunded bonus
+    ep = c["episodes"]
+    assert abs(c["sum_reward"].sum() / ep - (3 * 1.0 + 0.001 * c["sum_refunded"].sum() / ep)) < 1e-6
+    assert np.all(c["sum_reward_sq"] > 0) and np.all(c["sum_score"] / ep > 10)
+    eng.close()
+
+
+_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from skyjo_rl_amd.distributed import make_sharded_env, gather_stats
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")  # two ranks share the one GPU of the test box: RCCL refuses that, gloo carries the record
+cfg = dict(num_players=3, score_penalty=2.0, observe_other_player_indirect=True, mean_reward=1.0, reward_refunded=0.001, rng_mode=0, auto_reset=True)
+eng = make_sharded_env(4096, rank, world, device=0, **cfg)
+eng.seed(None, 5)
+eng.rollout(400, policy_seed=2)
+c = eng.counters()
+per_rank, tot = gather_stats(c, 3, device=torch.device("cuda", 0))
+if rank == 0:
+    print("RESULT " + json.dumps(dict(steps=float(tot["steps"]), episodes=float(tot["episodes"]), sum_len=float(tot["sum_len"]),
+          sum_reward=[float(x) for x in tot["sum_reward"]], sum_score=[float(x) for x in tot["sum_score"]], ranks=per_rank.shape[0])))
+eng.close()
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gather_of_product_engines_equals_single_process():
+    """Two processes, each with the PRODUCT engine for its shard (same GPU), all-gather their statistics record
+    (skyjo_rl_amd.distributed.gather_stats); the totals equal those of one process running all 4096 games."""
+    import json
+
+    script = _WORKER.format(root=ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29731", _write_tmp(script)], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    got = json.loads(line[7:])
+    eng = _engine(4096, **CFG)
+    eng.seed(None, 5)
+    eng.rollout(400, policy_seed=2)
+    c = eng.counters()
+    assert got["ranks"] == 2
+    assert got["steps"] == c["steps"] and got["episodes"] == c["episodes"] and got["sum_len"] == c["sum_len"]
+    np.testing.assert_allclose(got["sum_score"], c["sum_score"], rtol=0, atol=1e-6)  # (integer-valued: exact up to the order of float adds)
+    np.testing.assert_allclose(got["sum_reward"], c["sum_reward"], rtol=1e-12)
+    eng.close()
+
+
+def _write_tmp(text):
+    import tempfile
+
+    f = tempfile.NamedTemporaryFile("w", suffix="_skyjo_worker.py", delete=False)
+    f.write(text)
+    f.close()
+    return f.name
+
+
+def test_snapshot_restore_round_trip():
+    """Snapshot at t, run 300 iterations, restore, run them again: identical records, actions and counters - the
+    snapshot holds the RNG streams with their positions, the banks of pre-dealt episodes and the policy counter."""
+    import torch
+
+    B, K = 4096, 100
+    eng = _engine(B, **CFG)
+    eng.seed(None, 11)
+    eng.rollout(137, policy_seed=4)  # somewhere in the middle of things (banks partly used, dealing cycle under way)
+    snap = eng.snapshot()
+    assert snap.nbytes > B * (288 * 4 + 2496)
+    c0 = eng.counters()
+
+    def run():
+        recs = []
+        for r in range(3):
+            rec = eng.new_records(K)
+            eng.rollout(K, policy_seed=4, records=rec)
+            recs.append(rec)
+        return torch.stack(recs), eng.counters()
+
+    a, ca = run()
+    eng.restore(snap)
+    cr = eng.counters()
+    for k in ("steps", "episodes", "resets", "sum_len", "iters"):
+        assert cr[k] == c0[k], k
+    b, cb = run()
+    assert torch.equal(a, b)
+    for k in ("steps", "episodes", "resets", "sum_len", "waits"):
+        assert ca[k] == cb[k], k
+    np.testing.assert_array_equal(ca["sum_reward"], cb["sum_reward"])
+    assert ca["episodes"] > c0["episodes"] + B  # the window held resets, i.e. bank hand-overs and deals
+    # a single-game view after a restore sees the restored game
+    s1 = eng.get_state(5)
+    eng.rollout(10, policy_seed=4)
+    eng.restore(snap)
+    eng.rollout(3 * K, policy_seed=4)
+    s2 = eng.get_state(5)
+    for k in ("cards", "masked", "draw", "disc"):
+        np.testing.assert_array_equal(s1[k], s2[k])
+    snap.close()
+    eng.close()
+
+
+def test_handle_runs_on_its_device_from_any_thread():
+    """every entry point switches to the handle's device and restores the caller's.  On this one-GPU box the
+    observable part is: calls from a fresh thread (whose current device was never set) work and leave torch's current
+    device alone; a handle for a device that does not exist is refused."""
+    import torch
+    from skyjo_rl_amd import SkyjoNativeError
+
+    eng = _engine(64, **CFG)
+    eng.seed(None, 1)
+    out = {}
+
+    def worker():
+        try:
+            o = eng.observe_host()
+            o2 = eng.step_host(np.full(64, 24, dtype=np.int32))
+            out["ok"] = bool((o.phase == 0).all() and (o2.phase == 1).all())
+            out["state"] = eng.get_state(3)["phase"]
+            out["counters"] = eng.counters()["steps"]
+        except Exception as e:  # pragma: no cover
+            out["err"] = repr(e)
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert out.get("ok") and out["state"] == 1 and out["counters"] == 64, out
+    assert torch.cuda.current_device() == 0
+    with pytest.raises(SkyjoNativeError):
+        _engine(64, device=torch.cuda.device_count(), **CFG)
+    eng.close()

@@ -1,180 +1,45 @@
-"""Host-side mirrors of the reference interface (skyjo_rl_amd/aec_env.py, game.py, policy.py) driven
-by the oracle engine on CPU; compared with env-level golden vectors recorded from the reference
-(SimpleSkyjoEnv on pettingzoo stand-ins - third-party wrapper semantics are "unpinned")."""
+"""Host-side mirrors of the reference interface (skyjo_rl_amd/aec_env.py, game.py, policy.py) driven by the oracle
+engine on CPU (tests/view_checks.py holds the assertions; tests/test_gpu_views.py runs the same ones on the HIP engine)."""
 import glob
 import os
-import warnings
-from itertools import product
 
 import numpy as np
 import pytest
 
-from skyjo_rl_amd import aec_env
-from skyjo_rl_amd.game import SkyjoGame
 from skyjo_rl_amd.policy import policy_ra
+from tests import view_checks as vc
 from tests.oracle_engine import OracleEngine
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-ENVS = sorted(glob.glob(os.path.join(GOLDEN, "env_*.npz")))
-
-
-def make_env(wrapped=True, **cfg):
-    eng = OracleEngine(1, auto_reset=False, **cfg)
-    return aec_env.SimpleSkyjoEnv(engine=eng, wrapped=wrapped, **cfg)
+ENVS = sorted(glob.glob(os.path.join(vc.GOLDEN, "env_*.npz")))
 
 
 @pytest.mark.parametrize("path", ENVS, ids=[os.path.basename(p)[:-4] for p in ENVS])
 def test_env_golden(path):
-    """tests/environment/test_skyjo_env_jit.py flow: env.seed(s); rng=default_rng(s); reset; agent_iter/last/step."""
-    d = np.load(path)
-    cfg = dict(num_players=int(d["num_players"]), score_penalty=float(d["score_penalty"]),
-               observe_other_player_indirect=bool(d["indirect"]), mean_reward=float(d["mean_reward"]),
-               reward_refunded=float(d["reward_refunded"]))
-    e = make_env(**cfg)
-    seed = int(d["seed"])
-    e.seed(seed)
-    rng = np.random.default_rng(seed)
-    illegal = "illegal" in path
-    row = 0
-    for ep in range(len(d["ep_start"]) - 1):
-        e.reset()
-        for agent in e.agent_iter(max_iter=300 * cfg["num_players"]):
-            obs, reward, done, info = e.last()
-            assert int(agent.split("_")[-1]) == d["agent"][row], row
-            assert int(done) == d["done"][row], row
-            assert float(reward) == d["cum_reward"][row], (row, reward, d["cum_reward"][row])
-            np.testing.assert_array_equal(obs["observations"], d["obs"][row], err_msg=f"row {row}")
-            np.testing.assert_array_equal(obs["action_mask"], d["mask"][row], err_msg=f"row {row}")
-            assert obs["observations"].dtype == np.int8 and obs["action_mask"].dtype == np.int8
-            if not done:
-                a = int(policy_ra(obs["observations"], obs["action_mask"], rng=rng))
-                if illegal:
-                    a = int(d["action"][row])  # the fixture replaced one sampled action by an illegal one
-                assert a == d["action"][row], row
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore")
-                    e.step(a)
-            else:
-                e.step(None)
-            row += 1
-        assert row == d["ep_start"][ep + 1]
-        assert e.agents == []
+    vc.check_env_golden(OracleEngine, path)
 
 
 def test_reproducibility_like_reference():
-    """tests/environment/test_skyjo_env_jit.py:10-45: two seeded runs give identical observations and rewards."""
-    runs = []
-    for _ in range(2):
-        e = make_env(**aec_env.DEFAULT_CONFIG)
-        e.seed(42)
-        rng = np.random.default_rng(42)
-        e.reset()
-        obs_list, rewards = [], []
-        for agent in e.agent_iter(max_iter=300 * 3):
-            obs, reward, done, info = e.last()
-            if not done:
-                obs_list.append(obs["observations"])
-                e.step(policy_ra(obs["observations"], obs["action_mask"], rng=rng))
-            else:
-                e.step(None)
-                rewards.append(reward)
-        runs.append((obs_list, rewards))
-    np.testing.assert_array_equal(runs[0][0], runs[1][0])
-    np.testing.assert_array_equal(runs[0][1], runs[1][1])
-    # anchors observed when the reference itself is run this way
-    assert len(runs[0][0]) == 89
-    np.testing.assert_allclose(runs[0][1], [29.66666666666667, -70.33333333333333, 43.66666666666667], rtol=0, atol=0)
+    vc.check_reproducibility(OracleEngine)
 
 
 def test_config_sweep_like_reference():
-    """tests/environment/test_skyjo_env_nojit.py: simple_episode over the 288-config grid terminates cleanly."""
-    grid = product(range(1, 13), [1.0, 2.0], [True, False], [-1, 0.0, 1.0], [0.0, 0.01])
-    rng = np.random.default_rng(0)
-    for count, (n, pen, ind, mr, rr) in enumerate(grid):
-        if count % 3:  # every third configuration keeps the CPU suite short; all 12 player counts are hit
-            continue
-        cfg = dict(num_players=n, score_penalty=pen, observe_other_player_indirect=ind, mean_reward=mr,
-                   reward_refunded=rr)
-        e = make_env(**cfg)
-        e.reset()
-        total, steps = 0.0, 0
-        for agent in e.agent_iter(max_iter=300 * n):
-            obs, reward, done, info = e.last()
-            if not done:
-                assert e.observation_space(agent)["observations"].shape == obs["observations"].shape
-                e.step(policy_ra(obs["observations"], obs["action_mask"], rng=rng))
-                steps += 1
-            else:
-                total += reward
-                e.step(None)
-        if e.agents == []:  # finished inside max_iter (N=12 games can exceed 300*N iterations)
-            bonus = rr * sum(e.table.game_metrics["num_refunded"]) if rr else 0.0
-            assert abs(total - (n * mr + bonus)) < 1e-9  # skyjo_env.py:307-312: rewards sum to N*mean_reward (+bonus)
-        if count % 48 == 0:
-            assert "render board" in e.render()
+    assert vc.check_config_sweep(OracleEngine, every=3) == 96  # every third configuration keeps the CPU suite short
 
 
 def test_call_order_and_bounds_checks():
-    """OrderEnforcing / AssertOutOfBounds behaviour of the wrapper stack (skyjo_env.py:22-25)."""
-    e = make_env(**aec_env.DEFAULT_CONFIG)
-    with pytest.raises(AssertionError):
-        e.step(24)  # before reset
-    e.reset()
-    with pytest.raises(AssertionError):
-        e.step(26)
-    with pytest.raises(AssertionError):
-        e.step(None)  # agent is not done
-    e.seed(3)
-    with pytest.raises(AssertionError):
-        e.observe("player_0")  # seed() requires a new reset
-    e.reset()
-    assert e.agent_selection in e.possible_agents and e.num_agents == 3 and e.max_num_agents == 3
-    sp = e.action_space(e.agent_selection)
-    assert sp.contains(25) and not sp.contains(26)
+    vc.check_call_order(OracleEngine)
 
 
 def test_core_view_matches_reference_core_loop():
-    """rlskyjo/game/sample_game.py loop on the SkyjoGame view; data from a golden trajectory."""
-    d = np.load(os.path.join(GOLDEN, "traj_N3_s42_ind.npz"))
-    eng = OracleEngine(1, num_players=3, observe_other_player_indirect=True, auto_reset=False)
-    g = SkyjoGame(3, 2.0, True, engine=eng)
-    g.set_seed(42)
-    assert g.obs_shape == (31,) and g.action_mask_shape == (26,)
-    np.testing.assert_array_equal(g.players_cards, d["deal_cards"][0])
-    t = 0
-    while not g.is_terminated:
-        pid, phase = g.expected_action
-        assert phase in ("draw", "place")
-        obs, mask = g.collect_observation(pid)
-        np.testing.assert_array_equal(obs, d["obs"][t])
-        np.testing.assert_array_equal(mask, d["mask"][t])
-        assert g.act(pid, int(d["action"][t])) == bool(d["game_over"][t])
-        t += 1
-    assert t == d["ep_start"][1]
-    m = g.get_game_metrics()
-    np.testing.assert_array_equal(m["final_score"], d["final_score"][0])
-    np.testing.assert_array_equal(m["num_refunded"], d["num_refunded"][0])
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        assert g.act(g.expected_action[0], 24) is True  # skyjo.py:316-321
-        assert w
-    # the core's assertions (skyjo.py:310-334)
-    g.reset()
-    pid = g.expected_action[0]
-    with pytest.raises(AssertionError):
-        g.act((pid + 1) % 3, 24)
-    with pytest.raises(AssertionError):
-        g.act(pid, 26)
-    with pytest.raises(AssertionError):
-        g.act(pid, 3)
-    g.act(pid, 24)
-    with pytest.raises(AssertionError):
-        g.act(pid, 25)
-    # render helpers produce text and never raise (tests/game/test_skyjo.py:12-18)
-    assert "action ids 0-25" in g.render_actions()
-    assert "Player 0" in g.render_player(0) and "u" in g.render_player(0, render_cards_open=True)
-    assert [SkyjoGame.render_action_explainer(a) for a in range(26)][24] == "draw from drawpile"
-    assert "next turn: place" in g.render_table()
+    vc.check_core_view(OracleEngine)
+
+
+def test_core_view_on_one_game_of_a_shared_engine():
+    vc.check_core_view(OracleEngine, num_envs=5, index=3)
+
+
+def test_render_strings_match_reference():
+    assert vc.check_render_golden(OracleEngine) >= 20
 
 
 def test_policy_ra_matches_numpy_choice():

@@ -11,7 +11,7 @@ for rnd in range(3):
         for x in kv:
             k, v = x.split("=")
             env[k] = v
-        out = subprocess.run([sys.executable, "bench.py", "--steps", "3200", "--warmup", "320", "--no-cpu-baseline"] + extra, env=env,
+        out = subprocess.run([sys.executable, "bench.py", "--steps", "40", "--warmup", "5", "--no-cpu-baseline"] + extra, env=env,
                              capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
