@@ -3,12 +3,12 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A bench "step" is ONE FUSED LAUNCH of the hot path over the whole batch: `iterations_per_launch` (80)
+A bench "step" is ONE FUSED LAUNCH of the hot path over the whole batch: `iterations_per_step` (88)
 lockstep iterations - in each of them every live game applies one action chosen by the on-device
 random admissible policy (state transition + observation / action-mask build, the 64-byte record
 with the applied action written to HBM) and finished games take their next deal - plus the dealing
-run (k_scan + k_deal) that the engine starts once per 80 iterations.  So `--steps 20 --warmup 5` are
-1 600 timed lockstep iterations after 400 untimed ones (about 15 episodes per game inside the timed
+run (k_scan + k_deal) that the engine starts once per 88 iterations.  So `--steps 20 --warmup 5` are
+1 760 timed lockstep iterations after 440 untimed ones (about 16 episodes per game inside the timed
 region); the defaults are 250 / 25 launches.  The workload is BASELINE.json configs[2]: 65 536
 parallel 3-player games per GPU, DEFAULT_CONFIG (indirect observation, D = 31), game g seeded
 base + g, numpy-legacy MT19937 deals (bit-identical to the reference).  `value` = env-steps (applied
@@ -38,8 +38,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
-CHUNK = int(os.environ.get("SKYJO_BENCH_CHUNK", "80"))  # lockstep iterations per kernel launch (<= kMaxRolloutChunk in skyjo_capi.hip;
-                                                         # 80 = the engine's dealing interval for 3 and more players)
+CHUNK = int(os.environ.get("SKYJO_BENCH_CHUNK", "0"))  # lockstep iterations per kernel launch; 0 = the engine's dealing interval
+                                                        # (88 for three and more players, <= kMaxRolloutChunk in skyjo_capi.hip)
 
 
 def algorithmic_bytes_per_launch(B, N, D, iters, records=True):
@@ -98,7 +98,7 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=250, help="timed fused launches of 80 lockstep iterations each")
+    ap.add_argument("--steps", type=int, default=250, help="timed fused launches of 88 lockstep iterations each")
     ap.add_argument("--warmup", type=int, default=25, help="untimed launches before them")
     ap.add_argument("--num-envs", type=int, default=65536, help="games per GPU")
     ap.add_argument("--num-players", type=int, default=3)
@@ -142,7 +142,7 @@ def main():
     assert eng.num_envs == B and eng.game_id0 == rank * B
     eng.seed(None, 0)
     global CHUNK
-    CHUNK = min(CHUNK, eng.deal_interval())  # one launch per dealing cycle (64 iterations below three players / beside-the-step dealing)
+    CHUNK = min(CHUNK, eng.deal_interval()) if CHUNK > 0 else eng.deal_interval()  # one launch per dealing cycle
     D = eng.obs_dim
     record = not args.no_records
     rec = eng.new_records(CHUNK) if record else None           # [CHUNK, B, 64] ring reused by every launch
@@ -197,7 +197,7 @@ def main():
     achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")
-    if os.path.exists(tpath) and B == 65536 and N == 3 and record and act is None and CHUNK == 80:  # (the PMC passes ran this very launch shape)
+    if os.path.exists(tpath) and B == 65536 and N == 3 and record and act is None and CHUNK == 88:  # (the PMC passes ran this very launch shape)
         traffic = json.load(open(tpath)).get("k_step_bytes_per_launch")
     kernel_ms = {k: prof[k + "_ms"] / 32.0 for k in ("k_step", "k_scan", "k_deal", "k_publish")}  # per bench step (= per dealing cycle)
     path_ms = sum(kernel_ms.values())

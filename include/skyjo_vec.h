@@ -258,6 +258,16 @@ int skyjo_vec_mlp_forward(const skyjo_vec_mlp *m, const void *records, int32_t r
 int skyjo_vec_mlp_act(skyjo_vec *h, const skyjo_vec_mlp *m, const void *records, int64_t n, uint64_t seed, uint64_t ticket,
                       int32_t no_masking, int32_t *actions_out, float *logp_out, float *logits_out, void *stream);
 
+/* Policy AND value branch of the action-mask model (two nets of skyjo_vec_mlp_create over the same records) in ONE
+ * launch: the draw of skyjo_vec_mlp_act for the policy net, values_out float32 [n][value out_dim] for the other. */
+int skyjo_vec_mlp_act_value(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, const void *records, int64_t n,
+                            uint64_t seed, uint64_t ticket, int32_t no_masking, int32_t *actions_out, float *logp_out,
+                            float *logits_out, float *values_out, void *stream);
+/* Rollout collection: for the records a step has just written (device, [num_envs][record_bytes]) mark the games whose
+ * episode ended in that step - episode_end_out uint8 [num_envs] - and copy their final rewards (skyjo_env.py:293-312)
+ * into final_rewards_out double [num_envs][num_players], zeros elsewhere.  One small kernel, no host traffic. */
+int skyjo_vec_episode_ends(skyjo_vec *h, const void *records, double *final_rewards_out, uint8_t *episode_end_out, void *stream);
+
 /* host-pointer conveniences for small batches (single-game AEC view): synchronous */
 int skyjo_vec_step_host(skyjo_vec *h, const int32_t *actions_host, void *records_out_host);
 int skyjo_vec_observe_host(skyjo_vec *h, const int32_t *players_host, void *records_out_host);

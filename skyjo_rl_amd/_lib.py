@@ -72,6 +72,8 @@ SIGNATURES = {
     "skyjo_vec_mlp_destroy": (C.c_int, [VP]),
     "skyjo_vec_mlp_forward": (C.c_int, [VP, VP, I32, I64, VP, VP]),
     "skyjo_vec_mlp_act": (C.c_int, [VP, VP, VP, I64, U64, U64, I32, VP, VP, VP, VP]),
+    "skyjo_vec_mlp_act_value": (C.c_int, [VP, VP, VP, VP, I64, U64, U64, I32, VP, VP, VP, VP, VP]),
+    "skyjo_vec_episode_ends": (C.c_int, [VP, VP, VP, VP, VP]),
     "skyjo_vec_rewards_ptr": (VP, [VP]),
     "skyjo_vec_scores_ptr": (VP, [VP]),
     "skyjo_vec_done_ptr": (VP, [VP]),

@@ -4,10 +4,12 @@ Restates ``TorchActionMaskModel`` (rlskyjo/models/action_mask_model.py:13-77) wi
 default fully connected net (two tanh layers of 256 units, separate value branch) on
 ``obs["observations"]``, and ``logits + clamp(log(action_mask), min=FLOAT_MIN)`` as in :58-74.  It
 consumes the zero-copy views of the engine's record tensor directly on the GPU (``SkyjoVecEnv.split``),
-so a PPO-style rollout never leaves the device.  This is caller code, not part of the accelerated
-path; MFMA work (the three small GEMMs) is left to PyTorch-ROCm / hipBLASLt.  The masking + categorical
-draw has a fused HIP form behind the C ABI (``skyjo_vec_sample_actions``, ``sample_actions_fused`` below);
-``forward`` / ``sample_actions`` are the plain-torch statement of the same arithmetic and its test reference.
+so a PPO-style rollout never leaves the device.  ``ActionMaskModel`` / ``sample_actions`` are the plain-torch
+statement of the model (float32) and the test reference.  Behind the C ABI the same model runs as hand-written
+gfx950 kernels: ``FusedNet`` packs one branch for the matrix cores (``skyjo_vec_mlp_*``, csrc/skyjo_policy.h: bf16
+weights and activations, float32 accumulation - a documented deviation from the float32 module, tolerances in
+tests/test_gpu_policy_net.py), ``FusedNet.act`` adds the masking + categorical draw in the net's epilogue, and with
+``value_net=`` the value branch rides in the same launch (``skyjo_vec_mlp_act_value``).
 """
 import torch
 from torch import nn
@@ -97,16 +99,25 @@ class FusedNet:
                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return out
 
-    def act(self, env, records, seed=0, ticket=0, no_masking=False, actions=None, logp=None, logits=None):
-        """Policy branch + masked categorical draw in one launch (``skyjo_vec_mlp_act``): int32 actions for ``env.step``."""
+    def act(self, env, records, seed=0, ticket=0, no_masking=False, actions=None, logp=None, logits=None, value_net=None,
+            values=None):
+        """Policy branch + masked categorical draw in one launch (``skyjo_vec_mlp_act``): int32 actions for ``env.step``.
+        With ``value_net`` (the ``FusedNet`` of the value branch) and ``values`` (float32 [n, 1]) the value estimates of
+        the same records are computed by the same launch (``skyjo_vec_mlp_act_value``)."""
         n = records.numel() // records.shape[-1]
         if actions is None:
             actions = torch.empty((n,), dtype=torch.int32, device=records.device)
         C = self._C
         vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        self._check(self._L.skyjo_vec_mlp_act(env._h, self._h, vp(records), n, int(seed), int(ticket), 1 if no_masking else 0,
-                                              vp(actions), vp(logp), vp(logits),
-                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if value_net is not None:
+            assert values is not None and values.numel() == n * value_net.out_dim and values.dtype == torch.float32
+            self._check(self._L.skyjo_vec_mlp_act_value(env._h, self._h, value_net._h, vp(records), n, int(seed), int(ticket),
+                                                        1 if no_masking else 0, vp(actions), vp(logp), vp(logits), vp(values),
+                                                        stream))
+        else:
+            self._check(self._L.skyjo_vec_mlp_act(env._h, self._h, vp(records), n, int(seed), int(ticket), 1 if no_masking else 0,
+                                                  vp(actions), vp(logp), vp(logits), stream))
         return actions
 
     def close(self):

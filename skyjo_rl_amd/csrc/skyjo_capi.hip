@@ -48,12 +48,13 @@ constexpr int kMaxRolloutChunk = 128;  // lockstep iterations per k_step launch 
 // Default number of lockstep iterations between two dealing runs.  A run adds one episode to every bank that is not
 // full, so the interval has to stay below the mean episode length of the policy in use (random admissible policy:
 // 76 / 105 / 134 steps for 2 / 3 / 4 players) or the banks of SK_BANK episodes drain and finished games deal in
-// place (deal_inline: slow, same result).  Measured at 65 536 three-player games: 64 -> 20.3, 80 -> 21.6,
-// 96 -> 21.9 x 10^9 steps/s, 104 and more drain.
+// place (deal_inline: slow, same result).  Measured at 65 536 three-player games (round 2 kernels): 80 -> 23.8, 88 -> 24.5,
+// 92 -> 24.9, 96 -> 25.0 x 10^9 steps/s; over 2 x 10^8 episodes 88 and 92 never emptied a bank, 96 did 35 times in
+// 1.2 x 10^8 episodes: 88 it is (0.84 of the mean episode length, like 64 for two players).
 // With the dealing kernel on its own stream a run's episodes arrive one interval later, so the interval is a step
 // shorter there (the runs are hidden behind the step kernel anyway).
 constexpr int deal_interval_default(int num_players, bool overlap) {
-  return overlap ? (num_players >= 3 ? 64 : 48) : (num_players >= 3 ? 80 : 64);
+  return overlap ? (num_players >= 3 ? 64 : 48) : (num_players >= 3 ? 88 : 64);
 }
 
 }  // namespace
@@ -285,8 +286,9 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   h->G = (size_t)P.tiles * SK_TILE;
   h->lds_tile = (size_t)P.L.chunks * 1024;
   // tile + one iteration's records (64 B each, or rec_bytes + 16 for the direct observation; the rare paths' RNG scratch
-  // aliases this area) + the wavefront's per-seat float64 statistics
-  h->lds_bytes = h->lds_tile + (size_t)SK_TILE * (P.L.indirect ? 64 : P.L.rec_bytes + 16) + (size_t)SK_ACC_KINDS * cfg->num_players * 8;
+  // aliases this area) + per-lane per-seat float64 statistics
+  h->lds_bytes = h->lds_tile + (size_t)SK_TILE * (P.L.indirect ? 64 : P.L.rec_bytes + 16) + (size_t)SK_ACC_KINDS * cfg->num_players * 512;
+  if (const char *e = getenv("SKYJO_LDS_PAD")) h->lds_bytes += (size_t)atoi(e);  // diagnostic: caps the wavefronts per CU
   const size_t rec16 = (size_t)P.tiles * P.L.chunks * SK_TILE;
   if ((uint64_t)SK_BANK * rec16 * 16 >= (1ull << 32)) {  // (LDS-DMA addresses the bank with 32-bit offsets)
     delete h;
@@ -673,7 +675,7 @@ int skyjo_vec_mlp_forward(const skyjo_vec_mlp *m, const void *records, int32_t r
   DevGuard guard_(m->device_id);
   SkMlpDraw nodraw{};
   hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT - 1) / (32 * SKP_GT))), dim3(64), 0, (hipStream_t)stream, m->net,
-                     (const uint8_t *)records, (int)record_bytes, m->obs_dim, (long long)n, out, nodraw);
+                     (const uint8_t *)records, (int)record_bytes, m->obs_dim, (long long)n, out, nodraw, m->net, (float *)nullptr);
   HIPCHK(hipGetLastError());
   return SKYJO_OK;
 }
@@ -688,7 +690,36 @@ int skyjo_vec_mlp_act(skyjo_vec *h, const skyjo_vec_mlp *m, const void *records,
   d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = ticket;
   d.game_id0 = h->P.game_id0, d.actions = actions_out, d.logp = logp_out;
   hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT - 1) / (32 * SKP_GT))), dim3(64), 0, (hipStream_t)stream, m->net,
-                     (const uint8_t *)records, (int)h->P.L.rec_bytes, m->obs_dim, (long long)n, logits_out, d);
+                     (const uint8_t *)records, (int)h->P.L.rec_bytes, m->obs_dim, (long long)n, logits_out, d, m->net, (float *)nullptr);
+  HIPCHK(hipGetLastError());
+  return SKYJO_OK;
+}
+
+int skyjo_vec_mlp_act_value(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, const void *records, int64_t n,
+                            uint64_t seed, uint64_t ticket, int32_t no_masking, int32_t *actions_out, float *logp_out,
+                            float *logits_out, float *values_out, void *stream) {
+  if (!h || !policy || !value || !records || !actions_out || !values_out || n < 0)
+    return fail(SKYJO_E_INVALID, "skyjo_vec_mlp_act_value: bad argument");
+  GUARD(h);
+  if (policy->net.out_dim != SKYJO_NUM_ACTIONS) return fail(SKYJO_E_INVALID, "the policy net needs 26 outputs");
+  if (policy->obs_dim != value->obs_dim || policy->device_id != value->device_id || policy->device_id != h->cfg.device_id)
+    return fail(SKYJO_E_INVALID, "policy and value net must share the observation size and the engine's device");
+  if (n == 0) return SKYJO_OK;
+  SkMlpDraw d{};
+  d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = ticket;
+  d.game_id0 = h->P.game_id0, d.actions = actions_out, d.logp = logp_out;
+  hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT - 1) / (32 * SKP_GT)), 2), dim3(64), 0, (hipStream_t)stream,
+                     policy->net, (const uint8_t *)records, (int)h->P.L.rec_bytes, policy->obs_dim, (long long)n, logits_out, d,
+                     value->net, values_out);
+  HIPCHK(hipGetLastError());
+  return SKYJO_OK;
+}
+
+int skyjo_vec_episode_ends(skyjo_vec *h, const void *records, double *final_rewards_out, uint8_t *episode_end_out, void *stream) {
+  if (!h || !records || !final_rewards_out || !episode_end_out) return fail(SKYJO_E_INVALID, "null argument");
+  GUARD(h);
+  hipLaunchKernelGGL(k_episode_ends, dim3((h->P.B + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->P, (const uint8_t *)records,
+                     final_rewards_out, episode_end_out);
   HIPCHK(hipGetLastError());
   return SKYJO_OK;
 }

@@ -536,10 +536,11 @@ __device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *l
 // _evaluate_game + _calc_final_rewards (skyjo.py:477-498, skyjo_env.py:293-312), float64, no FMA
 // contraction (compiled with -ffp-contract=off), numpy's pairwise summation order for the mean.
 // ------------------------------------------------------------------------------------------
-// Per-WAVEFRONT float64 statistics (SK_ACC_KINDS x N doubles behind the record staging area): seat p of kind k at
-// ap + (k * N + p) * 8.  Only lanes whose game has just ended add to them (about one lane every second iteration),
-// as fire-and-forget LDS atomics - the few lanes that meet on one address are serialised by the LDS unit.
-#define ACC(k) (*(double *)(ap + ((k) << 3)))
+// Per-LANE float64 statistics (SK_ACC_KINDS x N doubles per lane behind the record staging area): element k of lane l at
+// ap + k * 512 (ap = base + l * 8).  Only lanes whose game has just ended add to them, as fire-and-forget LDS atomics on
+// lane-private addresses.  (One shared set per wavefront would save 6 KB of LDS, but for atomics on a wavefront-uniform
+// address the compiler emits a scalar loop over the active lanes per atomic - twelve loops per game end: k_step +10 %.)
+#define ACC(k) (*(double *)(ap + ((k) << 9)))
 __device__ __forceinline__ void acc_add(uint8_t *ap, int k, double v) {
   __hip_atomic_fetch_add(&ACC(k), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
@@ -714,7 +715,8 @@ __device__ __forceinline__ int policy_pick(int phase, const ObsRegs &o, uint32_t
 // v0..v2: the acting player's vis row (already loaded by the caller for the policy).
 // Caller guarantees the game is valid and not done.
 // ------------------------------------------------------------------------------------------
-template <bool INDIRECT, int NP>
+// TRUSTED: the action comes from policy_pick, which only ever returns legal actions - no legality test.
+template <bool INDIRECT, int NP, bool TRUSTED>
 __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uint8_t *fp, uint8_t *ap, HdrRegs &h, uint32_t v0,
                                              uint32_t v1, uint32_t v2, int a, int g, LaneCounters &cnt, Stamps &st) {
   const int N = P.L.N;
@@ -726,9 +728,9 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
   if (ua < 24u) {
     slot = a < 12 ? a : a - 12;
     sv = byte3(v0, v1, v2, slot);
-    legal = phase == 1 && (a < 12 ? sv != SKYJO_REFUNDED : sv == SKYJO_HAND_NONE);
+    legal = phase == 1 && (TRUSTED || (a < 12 ? sv != SKYJO_REFUNDED : sv == SKYJO_HAND_NONE));
   } else {
-    legal = ua <= 25u && phase == 0;
+    legal = (TRUSTED || ua <= 25u) && phase == 0;  // (a trusted pick is still refused in the wrong phase: a place turn with no slot left)
   }
   if (!legal) {  // offender gets illegal_reward, everybody else 0, all done
     double *rw = P.rewards + (size_t)g * N;
@@ -756,8 +758,12 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
     if (hidden_p == 0) {
       h.w0 |= (uint32_t)(F_TERMINATED | F_DONE) << 16;
       LB(H_FINISHER) = (uint8_t)p;
+#ifndef SK_EXP_NO_SCORE
       if (NP > 0 && NP < 8) finish_game_fixed<(NP > 0 && NP < 8) ? NP : 1>(P, lp, ap, g, p);
       else finish_game(P, lp, fp, ap, g, p);
+#else
+      P.done[g] = 1;
+#endif
       cnt.episodes++;
       cnt.sum_len += eplen;
 #ifdef SK_STAMPS_FINE
@@ -1021,8 +1027,8 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   // iteration's were read back (LDS executes a wavefront's accesses in order).
   uint8_t *stg = (uint8_t *)lds_raw + P.L.chunks * 1024;
   uint8_t *fp = stg + lane * 4;
-  uint8_t *ap = stg + (INDIRECT ? 4096 : SK_TILE * (P.L.rec_bytes + 16));
-  if (lane < SK_ACC_KINDS * P.L.N) ACC(lane) = 0.0;
+  uint8_t *ap = stg + (INDIRECT ? 4096 : SK_TILE * (P.L.rec_bytes + 16)) + lane * 8;
+  for (int k = 0; k < SK_ACC_KINDS * P.L.N; k++) ACC(k) = 0.0;
   STAMP_DECL;
 #ifdef SK_STEP_PRIO
   __builtin_amdgcn_s_setprio(SK_STEP_PRIO);  // ahead of a dealing wavefront that shares the SIMD
@@ -1062,7 +1068,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
 #ifndef SK_STAMPS_FINE
         STAMP(3);
 #endif
-        apply_action<INDIRECT, NP>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st);
+        apply_action<INDIRECT, NP, POLICY>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st);
 #ifdef SK_STAMPS_FINE
         STAMP(6);
 #else
@@ -1087,7 +1093,9 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
       } else {
         a = -1;
       }
-      obs_load(P, lp, (h.w0 >> 8) & 0xff, ob);  // one read of the row serves this record and the next iteration's turn
+      // One read of the expected player's row serves this record and the next iteration's turn.  A draw leaves both the
+      // player and his row as they were (the phase is 1 after an applied draw, 0 after a place, a reset or the final draw).
+      if (!((h.w0 & 0xffu) == 1u && (h.w0 >> 24) == SKYJO_ST_OK && a >= 24)) obs_load(P, lp, (h.w0 >> 8) & 0xff, ob);
       if (rec_out) {
         if (INDIRECT) {  // staged in LDS, written by the whole wavefront below
           uint4 rr[4];
@@ -1124,13 +1132,21 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
       // in it (k_step -7 %, k_deal -12 % together).  Staging slot of (record r, piece p): r * 64 + ((p + (r >> 1)) & 3)
       // * 16 - both the lane-per-record writes above and the lane-per-16-bytes reads here are bank-conflict free.
       typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+#ifdef SK_EXP_REC_WRAP
+      uint8_t *blk = rec_out + ((size_t)(it & 1) * P.B + (size_t)tile * SK_TILE) * 64;
+#else
       uint8_t *blk = rec_out + ((size_t)it * P.B + (size_t)tile * SK_TILE) * 64;
+#endif
       const int live = P.B - tile * SK_TILE;  // records of this tile that exist (the last tile may be partial)
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int r = 16 * j + (lane >> 2), p = lane & 3;
         const uint4 v = *(const uint4 *)(stg + r * 64 + ((p + (r >> 1)) & 3) * 16);
+#ifdef SK_EXP_REC_CACHED
+        if (r < live) *(u32x4_t *)(blk + j * 1024 + lane * 16) = (u32x4_t){v.x, v.y, v.z, v.w};
+#else
         if (r < live) __builtin_nontemporal_store((u32x4_t){v.x, v.y, v.z, v.w}, (u32x4_t *)(blk + j * 1024 + lane * 16));
+#endif
       }
     }
   }
@@ -1149,8 +1165,15 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   }
   // per-seat statistics of this launch: one slot per tile
   if (__any(cnt.episodes | cnt.illegal)) {
+    double mine = 0.0;
+    for (int k = 0; k < SK_ACC_KINDS * P.L.N; k++) {
+      double x = ACC(k);
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+      x = __shfl(x, 0, 64);
+      mine = lane == k ? x : mine;
+    }
     if (lane < SK_ACC_KINDS * P.L.N)  // lane = kind * N + seat -> slot kind * 12 + seat of the tile
-      P.acc_tile[(size_t)tile * SK_ACC_KINDS * SKYJO_MAX_PLAYERS + (lane / P.L.N) * SKYJO_MAX_PLAYERS + lane % P.L.N] += ACC(lane);
+      P.acc_tile[(size_t)tile * SK_ACC_KINDS * SKYJO_MAX_PLAYERS + (lane / P.L.N) * SKYJO_MAX_PLAYERS + lane % P.L.N] += mine;
   }
   STAMP(7);
   STAMP_STORE;
@@ -2000,6 +2023,17 @@ __global__ __launch_bounds__(SK_SAMPLE_BLOCK) void k_sample(SkLayout L, const ui
   actions[g] = sk_draw_action(row, mw, no_masking, seed, ticket, game_id0 + (uint64_t)g, logp ? &lp_ : nullptr, &u_);
   if (logp) logp[g] = lp_;
   if (uniform) uniform[g] = u_;
+}
+
+// Rollout collection: from the records a step has just written, mark the games whose episode ended in that
+// step (done, and not the record of a reset) and copy their final rewards (skyjo_env.py:293-312) - zeros elsewhere.
+__global__ void k_episode_ends(SkParams P, const uint8_t *rec, double *rew_out, uint8_t *end_out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P.B) return;
+  const uint8_t *meta = rec + (size_t)g * P.L.rec_bytes + P.L.Dp + 26;  // agent, phase, done, status
+  const bool end = meta[2] != 0 && meta[3] != SKYJO_ST_RESET && meta[3] != SKYJO_ST_NOOP_DONE;
+  end_out[g] = end ? 1 : 0;
+  for (int p = 0; p < P.L.N; p++) rew_out[(size_t)g * P.L.N + p] = end ? P.rewards[(size_t)g * P.L.N + p] : 0.0;
 }
 
 // records -> the reference's dense arrays (obs int8[n][D], mask int8[n][26], ...)

@@ -63,8 +63,15 @@ __device__ __forceinline__ skp_bf16x8 skp_frag(const uint4 *p) {
 // (half the weight traffic per game at 2, and two accumulators in flight instead of one dependent chain).
 // rec_bytes / obs_dim as in the engine's records (indirect observation: 31 int8 features).
 #define SKP_GT 1  // (2: 47.7 us vs 42.7 us per 65 536 records - the kernel is bound by its 512 tanh per game, not by weight traffic)
-__global__ __launch_bounds__(64) void k_mlp_forward(SkMlpDev net, const uint8_t *rec, int rec_bytes, int obs_dim, long long n,
-                                                     float *out, SkMlpDraw draw) {
+// A launch may carry TWO nets over the same records (grid.y = 2): workgroups with blockIdx.y == 1 evaluate `net_b` into
+// `out_b` (no draw) - the policy and the value branch of the action-mask model in one launch (skyjo_vec_mlp_act_value).
+__global__ __launch_bounds__(64) void k_mlp_forward(SkMlpDev net_a, const uint8_t *rec, int rec_bytes, int obs_dim, long long n,
+                                                     float *out_a, SkMlpDraw draw_a, SkMlpDev net_b, float *out_b) {
+  const bool second = blockIdx.y == 1;
+  const SkMlpDev net = second ? net_b : net_a;
+  float *out = second ? out_b : out_a;
+  SkMlpDraw draw = draw_a;
+  draw.enable = second ? 0 : draw_a.enable;
   const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
   long long g[SKP_GT];
   skp_bf16x8 x[SKP_GT][2];

@@ -1,12 +1,17 @@
-"""PPO-style rollout collection for config 5, all on the GPU: per lockstep iteration the policy and value
-nets run as MFMA kernels over the engine's records (``FusedNet``), the masked categorical draw is the fused HIP pass
-(``SkyjoVecEnv.sample_actions``) and the env step writes the next records straight into the buffer - no tensor of the
-rollout is ever touched by a torch kernel or the host.  What a learner needs per step of the acting seat
-(``rlskyjo/models/train_model_simple_rllib.py:22-59`` has RLlib collect the same columns): observation / action mask
-(inside the records), action, log-probability, value estimate, the acting agent, done flags and - at episode ends -
-the final rewards of skyjo_env.py:293-312 for every seat.
+"""PPO-style rollout collection for config 5, all on the GPU and all through the C ABI: per lockstep iteration
+ONE launch evaluates the policy branch with its masked categorical draw and the value branch on the matrix cores
+(``FusedNet.act(value_net=...)`` -> ``skyjo_vec_mlp_act_value``), ``skyjo_vec_step`` writes the next records straight into the
+buffer, and one small kernel (``skyjo_vec_episode_ends``) marks the episodes that ended and copies their final rewards - three
+launches per iteration, no torch kernel, no host traffic.  What a learner needs per step of the acting seat
+(``rlskyjo/models/train_model_simple_rllib.py:22-59`` has RLlib collect the same columns): observation / action mask (inside the
+records), action, log-probability, value estimate, the acting agent, done flags and - at episode ends - the final rewards of
+skyjo_env.py:293-312 for every seat.  ``RolloutBuffer.valid`` tells a learner which rows are transitions at all.
 """
+import ctypes as C
+
 import torch
+
+from . import _lib
 
 
 class RolloutBuffer:
@@ -16,17 +21,24 @@ class RolloutBuffer:
         dev = torch.device("cuda", env.device_index)
         B, N = env.num_envs, env.num_players
         self.T, self.B, self.N = T, B, N
+        self._env = env
         self.records = env.new_records(T + 1)                    # records[t] = what the actor of step t saw; [T] = bootstrap
         self.actions = torch.empty((T, B), dtype=torch.int32, device=dev)
         self.logp = torch.empty((T, B), dtype=torch.float32, device=dev)
         self.values = torch.empty((T + 1, B, 1), dtype=torch.float32, device=dev)
         self.final_rewards = torch.zeros((T, B, N), dtype=torch.float64, device=dev)  # non-zero rows where episode_end[t]
-        self.episode_end = torch.zeros((T, B), dtype=torch.bool, device=dev)
+        self.episode_end = torch.zeros((T, B), dtype=torch.uint8, device=dev)          # 1 where the step ended the episode
 
-    def views(self, env):
+    def views(self, env=None):
         """Zero-copy column views of the stored records: observations int8 [T+1, B, D], action_mask int8 [T+1, B, 26],
         agent / phase / done / status uint8 [T+1, B]."""
-        return env.split(self.records)
+        return (env or self._env).split(self.records)
+
+    @property
+    def valid(self):
+        """bool [T, B]: row t of game b is a transition.  Where ``records[t]`` already shows ``done`` the step only re-deals
+        the game (auto-reset: the action, log-probability and value stored for it were ignored) - mask those rows out."""
+        return self.views().done[: self.T] == 0
 
 
 @torch.no_grad()
@@ -34,19 +46,20 @@ def collect(env, policy, value, buf, seed=0, first_ticket=0, first_records=None)
     """Fill ``buf`` with T steps of the current policy.  ``policy`` / ``value``: ``FusedNet`` of the model's two
     branches.  ``first_records``: the records the rollout starts from (default: ``env.observe()``).  Returns ``buf``."""
     T = buf.T
+    L = _lib.load()
+    vp = lambda t: C.c_void_p(t.data_ptr())
     if first_records is None:
         env.observe(out=buf.records[0])
     else:
         buf.records[0].copy_(first_records)
     for t in range(T):
         rec = buf.records[t]
-        policy.act(env, rec, seed=seed, ticket=first_ticket + t, actions=buf.actions[t], logp=buf.logp[t])
-        value(rec, out=buf.values[t])
+        policy.act(env, rec, seed=seed, ticket=first_ticket + t, actions=buf.actions[t], logp=buf.logp[t], value_net=value,
+                   values=buf.values[t])
         env.step(buf.actions[t], out=buf.records[t + 1])
-        v = env.split(buf.records[t + 1])
         # a game that has just ended shows done = 1 in the record written by this step; its rewards stay valid until the
         # reset that the next step performs
-        buf.episode_end[t] = v.done.bool() & (v.status != 3)
-        buf.final_rewards[t] = env.rewards_tensor() * buf.episode_end[t].unsqueeze(-1)
+        _lib.check(L.skyjo_vec_episode_ends(env._h, vp(buf.records[t + 1]), vp(buf.final_rewards[t]), vp(buf.episode_end[t]),
+                                            env._stream()))
     value(buf.records[T], out=buf.values[T])
     return buf

@@ -35,7 +35,11 @@ def test_rollout_buffer_columns_are_consistent():
         ref = torch.log_softmax(logits + torch.clamp(torch.log(mask), min=torch.finfo(torch.float32).min), -1)
         assert float((ref.gather(1, a[t].unsqueeze(1)).squeeze(1) - buf.logp[t]).abs().max()) < 1e-5
         assert float((val(buf.records[t]) - buf.values[t]).abs().max()) == 0.0
-        ends = buf.episode_end
+        ends = buf.episode_end.bool()
+        # rows whose record already showed done are re-deals, not transitions: exactly the steps after an episode end
+        valid = buf.valid
+        assert bool((~valid[1:] == ends[:-1]).all())
+        assert bool((v.status[1:T + 1][~valid] == 3).all())  # the step of an invalid row only re-dealt the game
         if rnd == 2:
             assert int(ends.sum()) > 0
         rw = buf.final_rewards[ends]                                               # [episodes, N]

@@ -6,7 +6,7 @@ out=$PWD/gpurun_out/pmc_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$out" -- python3 "$OLDPWD/bench.py" --steps 160 --warmup 80 --no-cpu-baseline "$@" > "$out/bench.json" 2> "$out/bench.err"
+rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$out" -- python3 "$OLDPWD/bench.py" --steps 30 --warmup 10 --no-cpu-baseline "$@" > "$out/bench.json" 2> "$out/bench.err"
 echo "rc=$?"
 cd "$OLDPWD"
 f=$(find "$out" -name "*counter_collection.csv" | head -1)

@@ -7,7 +7,7 @@ out=$PWD/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python3 "$OLDPWD/bench.py" --steps 800 --warmup 80 --no-cpu-baseline "$@" > "$out/bench.json" 2> "$out/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python3 "$OLDPWD/bench.py" --steps 100 --warmup 10 --no-cpu-baseline "$@" > "$out/bench.json" 2> "$out/bench.err"
 echo "rc=$?"
 cd "$OLDPWD"
 find "$out" -name "*kernel_stats*.csv" | head -3
