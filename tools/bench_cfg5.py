@@ -2,8 +2,9 @@
 (rlskyjo/models/action_mask_model.py:13-77 restated without Ray, RLlib's default 256-256 tanh net, random weights)
 end-to-end on one GPU.  Per lockstep iteration: records -> zero-copy views -> policy net (torch / hipBLASLt GEMMs)
 -> masking + categorical draw -> skyjo_vec_step.  Two forms of the draw: plain torch (softmax + multinomial) and
-the fused HIP pass (skyjo_vec_sample_actions); "mfma" additionally runs the policy net as the hand-written MFMA
-kernel (skyjo_vec_mlp_forward) instead of torch.   python tools/bench_cfg5.py [B] [iters]"""
+the fused HIP pass (skyjo_vec_sample_actions); "mfma" runs the policy net as the hand-written MFMA kernel with the draw in
+its epilogue (skyjo_vec_mlp_act) instead of torch, "mfma_value" the policy AND the value branch in that one launch
+(skyjo_vec_mlp_act_value: what a PPO rollout needs per step).   python tools/bench_cfg5.py [B] [iters] [only-this-form]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,20 +16,26 @@ ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 torch.manual_seed(0)
 out = {"config": "65536 x 4 players, action-mask model in the loop" if B == 65536 else f"{B} x 4 players", "iters": ITERS}
 for dtype in (torch.float32, torch.bfloat16):
-    for form in ("torch", "fused", "mfma"):
-        if form == "mfma" and dtype != torch.bfloat16:
+    for form in ("torch", "fused", "mfma", "mfma_value"):
+        if form.startswith("mfma") and dtype != torch.bfloat16:
+            continue
+        if len(sys.argv) > 3 and not form.startswith(sys.argv[3]):
             continue
         env = SkyjoVecEnv(B, num_players=4)
         env.seed(None, 3)
         model = ActionMaskModel(obs_dim=env.obs_dim).cuda()
         rec = env.reset()
         gen = torch.Generator(device="cuda").manual_seed(1)
-        pol = FusedNet(model.policy) if form == "mfma" else None
+        pol = FusedNet(model.policy) if form.startswith("mfma") else None
+        val = FusedNet(model.value) if form == "mfma_value" else None
         act_buf = torch.empty((B,), dtype=torch.int32, device="cuda")
+        val_buf = torch.empty((B, 1), dtype=torch.float32, device="cuda")
 
         def one(t, rec):
             if form == "mfma":  # policy net on the matrix cores with the draw in its epilogue (skyjo_vec_mlp_act) + env step: 2 launches
                 return env.step(pol.act(env, rec, seed=9, ticket=t, actions=act_buf), out=rec)
+            if form == "mfma_value":  # the same launch also evaluates the value branch
+                return env.step(pol.act(env, rec, seed=9, ticket=t, actions=act_buf, value_net=val, values=val_buf), out=rec)
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
                 if form == "torch":
                     v = env.split(rec)

@@ -1,7 +1,7 @@
 """Diagnostic: k_step time per lockstep iteration while NO game can end (the first 60 iterations after seeding: the
 shortest episode is 61 steps) vs steady state (resets in ~45 % of the wavefront-iterations), with and without records."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from skyjo_rl_amd import SkyjoVecEnv
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536

@@ -1,6 +1,6 @@
 """Diagnostic: how the self-adapting dealing interval behaves for 2, 3 and 4 players (python tools/probe_interval.py)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from skyjo_rl_amd import SkyjoVecEnv
 for N in (3, 2, 4):

@@ -1,7 +1,7 @@
 """Diagnostic: where does a k_step wavefront spend its cycles?  Needs a -DSK_STAMPS build:
    hipcc ... -DSK_STAMPS -o /tmp/libskyjo_stamps.so ; SKYJO_LIB=/tmp/libskyjo_stamps.so python tools/stamps.py"""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from skyjo_rl_amd import SkyjoVecEnv, _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536

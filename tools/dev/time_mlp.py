@@ -1,6 +1,6 @@
 """Kernel time of skyjo_vec_mlp_forward (policy net on the matrix cores) at 65 536 records, torch events."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from skyjo_rl_amd import SkyjoVecEnv
 from skyjo_rl_amd.action_mask_model import ActionMaskModel, FusedNet

@@ -11,11 +11,16 @@ rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" --steps 800 --warmup 80 --no-cpu-baseline > "$out/trace_bench.json" 2> "$out/trace.err"; echo "trace rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" --steps 100 --warmup 10 --no-cpu-baseline > "$out/trace_bench.json" 2> "$out/trace.err"; echo "trace rc=$?"
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "sq2 SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS"; do
   set -- $pass; tag=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/pmc_$tag" -- python3 "$root/bench.py" --steps 160 --warmup 80 --no-cpu-baseline > "$out/pmc_$tag.json" 2> "$out/pmc_$tag.err"; echo "pmc $tag rc=$?"
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/pmc_$tag" -- python3 "$root/bench.py" --steps 30 --warmup 10 --no-cpu-baseline > "$out/pmc_$tag.json" 2> "$out/pmc_$tag.err"; echo "pmc $tag rc=$?"
 done
+# config 5 (65 536 x 4 players, the action-mask model on the matrix cores picks every action): bench line + kernel stats
+cd "$root"
+python3 tools/bench_cfg5.py 65536 300 > "$out/cfg5.json" 2> "$out/cfg5.err"; echo "cfg5 rc=$?"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_cfg5" -- python3 "$root/tools/bench_cfg5.py" 65536 100 mfma > "$out/cfg5_trace.json" 2> "$out/cfg5_trace.err"; echo "cfg5 trace rc=$?"
 cd "$root"
 # keep the merge-back small: only the csv summaries
 find "$out" -type f ! -name "*.csv" ! -name "*.json" ! -name "*.err" -delete
