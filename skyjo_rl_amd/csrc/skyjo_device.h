@@ -74,6 +74,8 @@ struct LaneCounters {
 // LDS addressing: lp = tile base + lane * 16 ; byte b of this lane's record lives at lp[LIDX(b)]
 // (chunk-major, skyjo_layout.h); LQ(c) is the lane's whole 16-byte chunk c (one ds_read_b128 / ds_write_b128).
 // ------------------------------------------------------------------------------------------
+#define SK_RARE(x) __builtin_expect(!!(x), 0)
+#define SK_OFTEN(x) __builtin_expect(!!(x), 1)
 #define LIDX(b) ((((b) >> 4) << 10) | ((b) & 15))
 #define LB(b) (lp[LIDX(b)])
 #define LI(b) ((int)(int8_t)lp[LIDX(b)])
@@ -755,6 +757,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
     int pile_top = LI(pb + pile_addr(role, nd > 0 ? nd - 1 : 0));
     const int disc_top = LI(pb + pile_addr(role ^ 1, ns > 0 ? ns - 1 : 0));
     const int disc_below = LI(pb + pile_addr(role ^ 1, ns > 1 ? ns - 2 : 0));
+
     if (hidden_p == 0) {
       h.w0 |= (uint32_t)(F_TERMINATED | F_DONE) << 16;
       LB(H_FINISHER) = (uint8_t)p;
@@ -774,7 +777,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
     const bool from_pile = a == 24;
     if (from_pile && nd == 0) {  // rare: works on the LDS copy of the header
       HDR_FLUSH(h);
-#ifndef SK_EXPERIMENT_NO_RARE
+#ifndef SK_EXP_NO_RARE
       reshuffle_dispatch(P, lp, fp, g);
 #endif
       HDR_LOAD(h);
@@ -1047,9 +1050,18 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   if (valid) obs_load(P, lp, (h.w0 >> 8) & 0xff, ob);
   for (int it = 0; it < iters; it++) {
     const uint64_t iter = iter0 + (uint64_t)it;
-    if (POLICY && (it == 0 || (iter & 3) == 0))
+    if (POLICY && (it == 0 || (iter & 3) == 0)) {
       philox4x32_10((uint32_t)(iter >> 2), (uint32_t)gid, (uint32_t)(gid >> 32), 0x504F4C00u, (uint32_t)policy_seed,
                     (uint32_t)(policy_seed >> 32), r0, r1, r2, r3);
+      for (int k = (int)(iter & 3); k > 0; k--) {  // (a launch may start inside a block of four: r0 is always the word of this iteration)
+        const uint32_t t = r0;
+        r0 = r1, r1 = r2, r2 = r3, r3 = t;
+      }
+    }
+    const uint32_t word = r0;
+    if (POLICY) {  // next iteration's word moves up (a select on the iteration number compiles to three scalar branches)
+      r0 = r1, r1 = r2, r2 = r3, r3 = word;
+    }
     int a = -1;
     if (valid) {
       const bool over = ((h.w0 >> 16) & F_DONE) != 0;
@@ -1061,10 +1073,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
       if (!over && !skip) {
         const uint32_t v0 = ob.q0, v1 = ob.q1, v2 = ob.q2;  // the acting player's row, read for the previous record
         STAMP(2);
-        if (POLICY) {
-          const uint32_t sel = (uint32_t)(iter & 3);
-          a = policy_pick(h.w0 & 0xff, ob, sel == 0 ? r0 : sel == 1 ? r1 : sel == 2 ? r2 : r3);
-        }
+        if (POLICY) a = policy_pick(h.w0 & 0xff, ob, word);
 #ifndef SK_STAMPS_FINE
         STAMP(3);
 #endif
@@ -1078,7 +1087,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
         a = -1;
         if (P.auto_reset) {
           if (!spare_commit(P, lp, g, sp)) {
-#ifndef SK_EXPERIMENT_NO_RARE
+#ifndef SK_EXP_NO_RARE
             deal_inline(P, lp, fp, g, tile, lane, sp.head);
 #endif
             cnt.waits++;  // counts the slow-path deals
@@ -1138,15 +1147,23 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
       uint8_t *blk = rec_out + ((size_t)it * P.B + (size_t)tile * SK_TILE) * 64;
 #endif
       const int live = P.B - tile * SK_TILE;  // records of this tile that exist (the last tile may be partial)
+      // all four pieces are requested before the first is used: ONE LDS round trip (guarded one by one, each read sat
+      // behind its own wait inside its own exec-masked block: four round trips and eight branches per iteration)
+      uint4 v[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int r = 16 * j + (lane >> 2), p = lane & 3;
-        const uint4 v = *(const uint4 *)(stg + r * 64 + ((p + (r >> 1)) & 3) * 16);
-#ifdef SK_EXP_REC_CACHED
-        if (r < live) *(u32x4_t *)(blk + j * 1024 + lane * 16) = (u32x4_t){v.x, v.y, v.z, v.w};
-#else
-        if (r < live) __builtin_nontemporal_store((u32x4_t){v.x, v.y, v.z, v.w}, (u32x4_t *)(blk + j * 1024 + lane * 16));
-#endif
+        v[j] = *(const uint4 *)(stg + r * 64 + ((p + (r >> 1)) & 3) * 16);
+      }
+      if (SK_OFTEN(live >= SK_TILE)) {  // (wavefront-uniform: a scalar branch)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          __builtin_nontemporal_store((u32x4_t){v[j].x, v[j].y, v[j].z, v[j].w}, (u32x4_t *)(blk + j * 1024 + lane * 16));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (16 * j + (lane >> 2) < live)
+            __builtin_nontemporal_store((u32x4_t){v[j].x, v[j].y, v[j].z, v[j].w}, (u32x4_t *)(blk + j * 1024 + lane * 16));
       }
     }
   }
