@@ -287,7 +287,8 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   h->lds_tile = (size_t)P.L.chunks * 1024;
   // tile + one iteration's records (64 B each, or rec_bytes + 16 for the direct observation; the rare paths' RNG scratch
   // aliases this area) + per-lane per-seat float64 statistics
-  h->lds_bytes = h->lds_tile + (size_t)SK_TILE * (P.L.indirect ? 64 : P.L.rec_bytes + 16) + (size_t)SK_ACC_KINDS * cfg->num_players * 512;
+  h->lds_bytes = h->lds_tile + (size_t)SK_TILE * (P.L.indirect ? 64 : P.L.rec_bytes + 16) + (size_t)SK_ACC_KINDS * cfg->num_players * 512 +
+                 (cfg->num_players < 8 ? (size_t)cfg->num_players * 1024 : 0);  // + the card chunks of games waiting to be scored
   if (const char *e = getenv("SKYJO_LDS_PAD")) h->lds_bytes += (size_t)atoi(e);  // diagnostic: caps the wavefronts per CU
   const size_t rec16 = (size_t)P.tiles * P.L.chunks * SK_TILE;
   if ((uint64_t)SK_BANK * rec16 * 16 >= (1ull << 32)) {  // (LDS-DMA addresses the bank with 32-bit offsets)

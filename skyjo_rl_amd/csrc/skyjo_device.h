@@ -24,6 +24,13 @@ struct SkCounters {
   double sum_refunded[SKYJO_MAX_PLAYERS];
 };
 #define SK_ERR_DEAL_TIMEOUT 1u  // bits of SkParams.dev_error
+// Deferred scoring: lockstep iterations between two service points (a power of two).  It must stay below the shortest
+// possible episode - 20 N + 1 steps (ten place turns of the finisher, everybody else in between, the final draw): 41 for
+// two players - so that no game can end twice between two service points.  4 / 8 / 16 / 32: k_step 134.7 / 128.3 / 125.2 /
+// 123.4 us per 88 iterations (139.8 with every game scored in the iteration it ends).
+#ifndef SK_SCORE_EVERY
+#define SK_SCORE_EVERY 32
+#endif
 #define SK_ACC_KINDS 4  // per-seat float64 statistics kept per tile: score, reward, reward^2, refunded
 
 // Pre-dealt episodes per game.  Deeper banks ride out longer gaps between dealing runs, but their records share the
@@ -591,15 +598,16 @@ __device__ __forceinline__ void finish_game(const SkParams &P, uint8_t *lp, uint
   P.done[g] = 1;
 }
 
-// The same for a compile-time player count: card rows come in as dwords, scores stay in registers.
+// The same for a compile-time player count: card rows come in as dwords, scores stay in registers.  `rows`: this lane's
+// card chunk of player 0, player p's `stride` bytes further - the live tile, or the copy a deferred scoring works on.
 template <int NP>
-__device__ __forceinline__ void finish_game_fixed(const SkParams &P, uint8_t *lp, uint8_t *ap, int g, int finisher) {
+__device__ __forceinline__ void finish_game_fixed(const SkParams &P, const uint8_t *rows, int stride, uint8_t *ap, int g, int finisher) {
   double *sc = P.scores + (size_t)g * NP, *rw = P.rewards + (size_t)g * NP;
   int s[NP], refunded[NP];
   int mn = 0, fs = 0;
 #pragma unroll
   for (int p = 0; p < NP; p++) {
-    const uint4 row = LQ(sk_pb(P.L, p) >> 4);  // cards + the player's counters in one read
+    const uint4 row = *(const uint4 *)(rows + p * stride);  // cards + the player's counters in one read
     const uint32_t c0 = row.x, c1 = row.y, c2 = row.z;
     refunded[p] = (int)(row.w >> 24);
     const uint32_t tri[4] = {c0 & 0xffffffu, (c0 >> 24) | ((c1 & 0xffffu) << 8), (c1 >> 16) | ((c2 & 0xffu) << 16), c2 >> 8};
@@ -628,7 +636,6 @@ __device__ __forceinline__ void finish_game_fixed(const SkParams &P, uint8_t *lp
     sc[p] = d[p], rw[p] = r;
     acc_episode(ap, NP, p, d[p], r, refunded[p]);
   }
-  P.done[g] = 1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -718,9 +725,13 @@ __device__ __forceinline__ int policy_pick(int phase, const ObsRegs &o, uint32_t
 // Caller guarantees the game is valid and not done.
 // ------------------------------------------------------------------------------------------
 // TRUSTED: the action comes from policy_pick, which only ever returns legal actions - no legality test.
+// `pendp` != nullptr: the scoring of a finished game is DEFERRED - its card chunks are copied to pendp (chunk of player p
+// at pendp + p * 1024) and the finisher is left in pend_fin; the caller scores all such games of the wavefront together
+// every few iterations (the float64 arithmetic of one or two lanes is a section the other 62 wait for).
 template <bool INDIRECT, int NP, bool TRUSTED>
 __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uint8_t *fp, uint8_t *ap, HdrRegs &h, uint32_t v0,
-                                             uint32_t v1, uint32_t v2, int a, int g, LaneCounters &cnt, Stamps &st) {
+                                             uint32_t v1, uint32_t v2, int a, int g, LaneCounters &cnt, Stamps &st,
+                                             uint8_t *pendp, int &pend_fin) {
   const int N = P.L.N;
   const int phase = h.w0 & 0xff, p = (h.w0 >> 8) & 0xff;
   const int blk = sk_pb(P.L, p), cardb = blk + PB_CARDS, visb = blk + PB_VIS, pb = P.L.off_pile;
@@ -762,8 +773,19 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
       h.w0 |= (uint32_t)(F_TERMINATED | F_DONE) << 16;
       LB(H_FINISHER) = (uint8_t)p;
 #ifndef SK_EXP_NO_SCORE
-      if (NP > 0 && NP < 8) finish_game_fixed<(NP > 0 && NP < 8) ? NP : 1>(P, lp, ap, g, p);
-      else finish_game(P, lp, fp, ap, g, p);
+      if (NP > 0 && NP < 8) {
+        constexpr int NQ = (NP > 0 && NP < 8) ? NP : 1;
+        P.done[g] = 1;
+        if (pendp) {
+#pragma unroll
+          for (int q = 0; q < NQ; q++) *(uint4 *)(pendp + q * 1024) = LQ(sk_pb(P.L, q) >> 4);
+          pend_fin = p;
+        } else {
+          finish_game_fixed<NQ>(P, lp + (P.L.off_players >> 4) * 1024, 2048, ap, g, p);
+        }
+      } else {
+        finish_game(P, lp, fp, ap, g, p);
+      }
 #else
       P.done[g] = 1;
 #endif
@@ -1031,6 +1053,10 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   uint8_t *stg = (uint8_t *)lds_raw + P.L.chunks * 1024;
   uint8_t *fp = stg + lane * 4;
   uint8_t *ap = stg + (INDIRECT ? 4096 : SK_TILE * (P.L.rec_bytes + 16)) + lane * 8;
+  // deferred scoring (fixed player counts under the on-device policy): one card chunk per player and lane behind the statistics
+  constexpr bool DEFER = POLICY && NP > 0 && NP < 8;
+  uint8_t *pendp = DEFER ? stg + (INDIRECT ? 4096 : SK_TILE * (P.L.rec_bytes + 16)) + SK_ACC_KINDS * P.L.N * 512 + lane * 16 : nullptr;
+  int pend_fin = -1;
   for (int k = 0; k < SK_ACC_KINDS * P.L.N; k++) ACC(k) = 0.0;
   STAMP_DECL;
 #ifdef SK_STEP_PRIO
@@ -1077,7 +1103,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
 #ifndef SK_STAMPS_FINE
         STAMP(3);
 #endif
-        apply_action<INDIRECT, NP, POLICY>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st);
+        apply_action<INDIRECT, NP, POLICY>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st, pendp, pend_fin);
 #ifdef SK_STAMPS_FINE
         STAMP(6);
 #else
@@ -1121,6 +1147,18 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
 #else
       STAMP(6);
 #endif
+    }
+    if (DEFER && ((it & (SK_SCORE_EVERY - 1)) == SK_SCORE_EVERY - 1 || it == iters - 1)) {
+      // Scores, rewards and statistics of the games that ended since the last service point (skyjo.py:477-498,
+      // skyjo_env.py:293-312), all lanes of the wavefront in one section.  A game cannot end twice in between (an episode
+      // is far longer than SK_SCORE_EVERY iterations and the on-device policy makes no illegal move), and the launch does
+      // not end before its last service point - the host never sees an unscored finished game.
+      if (SK_RARE(__any(pend_fin >= 0))) {
+        if (pend_fin >= 0) {
+          finish_game_fixed<(NP > 0 && NP < 8) ? NP : 1>(P, pendp, 1024, ap, g, pend_fin);
+          pend_fin = -1;
+        }
+      }
     }
     if (!INDIRECT && rec_out) {  // same idea for the wider records of the direct observation: rec_bytes / 16 pieces each
       typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
