@@ -50,6 +50,14 @@ def algorithmic_bytes_per_launch(B, N, D, iters, records=True):
     return B * (2 * S + iters * per_step)
 
 
+def rng_outputs_per_deal(N):
+    """Expected MT19937 outputs one deal consumes: shuffle(150), shuffle(150 - 12 N), N x permutation(12), each
+    step i of a legacy shuffle drawing until (u32 & mask) <= i (mask = next power of two - 1): (mask + 1) / (i + 1) draws."""
+    def shuffle(n):
+        return sum((1 << i.bit_length()) / (i + 1) for i in range(1, n))
+    return shuffle(150) + shuffle(150 - 12 * N) + N * shuffle(12)
+
+
 def cpu_baseline(num_players, seconds=12.0):
     """Oracle (kind 'port') on the host cores: same rollout (same policy restatement), bounded sample."""
     from oracle import skyjo_oracle as so
@@ -202,6 +210,10 @@ def main():
     kernel_ms = {k: prof[k + "_ms"] / 32.0 for k in ("k_step", "k_scan", "k_deal", "k_publish")}  # per bench step (= per dealing cycle)
     path_ms = sum(kernel_ms.values())
     wall_ms = 1e3 * t_max / args.steps
+    # the dealing kernel's own algorithmic traffic (MT19937 mode): per RNG output one state word read as the old element, one
+    # as element i + 397, one written (12 B), plus the 24N + 150 + 16 B record, for every deal consumed in the timed region
+    deals_per_step = float(c1["resets"]) / args.steps
+    deal_alg = deals_per_step * ((24 * N + 150 + 16) + (12.0 * rng_outputs_per_deal(N) if args.rng == "mt19937" else 0.0))
 
     if rank == 0:
         out = {
@@ -247,8 +259,16 @@ def main():
                               "wall_ms_per_step": wall_ms,
                               "achieved_wall": alg / (wall_ms * 1e-3) / 1e9,
                               "frac_wall": alg / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "note": "algorithmic bytes of one k_step launch over the time of one whole dealing cycle; with the dealing kernel "
-                                      "on its own stream the kernel times overlap and only the wall figure is a path time"},
+                              "k_deal": {"deals_per_step": deals_per_step, "rng_outputs_per_deal": rng_outputs_per_deal(N) if args.rng == "mt19937" else None,
+                                         "algorithmic_bytes_per_step": deal_alg,
+                                         "achieved": deal_alg / (kernel_ms["k_deal"] * 1e-3) / 1e9 if kernel_ms["k_deal"] > 0 else 0.0,
+                                         "frac": deal_alg / (kernel_ms["k_deal"] * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms["k_deal"] > 0 else 0.0},
+                              "achieved_wall_incl_dealing_bytes": (alg + deal_alg) / (wall_ms * 1e-3) / 1e9,
+                              "frac_wall_incl_dealing_bytes": (alg + deal_alg) / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "note": "achieved_* / frac_*: algorithmic bytes of one k_step launch (SURVEY 8d: state once + records) over the time of one "
+                                      "whole dealing cycle; *_incl_dealing_bytes adds the generator-state and record bytes the dealing kernel itself "
+                                      "has to move (not part of SURVEY 8d's per-step figure); with the dealing kernel on its own stream the kernel times "
+                                      "overlap and only the wall figures are path times"},
         }
         if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: a reported baseline, not part of the scaling runs)
             out["cpu_baseline"] = cpu_baseline(N)

@@ -220,6 +220,11 @@ int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
  * the batch leaves SIMDs idle (at most 640 tiles of 64 games), 0 on a full chip; environment override SKYJO_OVERLAP.
  * Results do not depend on this setting. */
 #define SKYJO_OPT_OVERLAP 2
+/* Fault injection for the tests (never needed in production): SKYJO_OPT_DEBUG_SPIN_LOG2 - a step kernel that has to wait
+ * for an overlapped dealing kernel gives up after 2^value polls (default 22) and raises the sticky device error that
+ * skyjo_vec_get_counters reports; SKYJO_OPT_DEBUG_DEAL_DELAY - every dealing wavefront sleeps value x 8128 cycles first. */
+#define SKYJO_OPT_DEBUG_SPIN_LOG2 3
+#define SKYJO_OPT_DEBUG_DEAL_DELAY 4
 int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value);
 int skyjo_vec_get_option(const skyjo_vec *h, int option, int64_t *value_out);
 

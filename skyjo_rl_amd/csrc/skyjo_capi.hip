@@ -283,6 +283,7 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   P.score_penalty = cfg->score_penalty, P.mean_reward = cfg->mean_reward;
   P.reward_refunded = cfg->reward_refunded, P.illegal_reward = cfg->illegal_reward;
   P.game_id0 = cfg->game_id0;
+  P.spin_log2 = 22, P.debug_deal_delay = 0;
   h->G = (size_t)P.tiles * SK_TILE;
   h->lds_tile = (size_t)P.L.chunks * 1024;
   // tile + one iteration's records (64 B each, or rec_bytes + 16 for the direct observation; the rare paths' RNG scratch
@@ -380,6 +381,7 @@ int skyjo_vec_seed(skyjo_vec *h, const uint64_t *seeds_host, uint64_t base_seed,
     HIPCHK(hipMemcpyAsync(d_seeds, seeds_host, sizeof(uint64_t) * (size_t)h->P.B, hipMemcpyHostToDevice, s));
   }
   HIPCHK(hipMemsetAsync(h->P.done, 0, h->G, s));
+  HIPCHK(hipMemsetAsync(h->P.dev_error, 0, sizeof(uint32_t), s));  // a new seeding starts from a clean slate
   int rc0;
   if ((rc0 = publish_deals(h, s))) return rc0;  // drain the dealing pipeline of the previous seeding, if any
   hipLaunchKernelGGL(k_seed, dim3((h->P.B + 255) / 256), dim3(256), 0, s, h->P, (const uint64_t *)d_seeds, base_seed, 0,
@@ -939,6 +941,14 @@ int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
       if (h->auto_interval) h->deal_every_iters = h->interval_default;
       return SKYJO_OK;
     }
+    case SKYJO_OPT_DEBUG_SPIN_LOG2:
+      if (value < 1 || value > 30) return fail(SKYJO_E_INVALID, "spin limit must be 2^1 .. 2^30");
+      h->P.spin_log2 = (uint32_t)value;
+      return SKYJO_OK;
+    case SKYJO_OPT_DEBUG_DEAL_DELAY:
+      if (value < 0 || value > (1 << 24)) return fail(SKYJO_E_INVALID, "deal delay out of range");
+      h->P.debug_deal_delay = (uint32_t)value;
+      return SKYJO_OK;
     default:
       return fail(SKYJO_E_INVALID, "unknown option");
   }

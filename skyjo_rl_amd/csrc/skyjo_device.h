@@ -45,6 +45,8 @@ struct SkParams {
   SkLayout L;
   int32_t B, tiles, rng_mode, auto_reset;
   uint32_t deal_tag;        // id of the dealing launch that may still be running while this kernel runs
+  uint32_t spin_log2;       // wait_deal_done gives up after 2^spin_log2 polls (22; lowered by the fault-injection test)
+  uint32_t debug_deal_delay;  // fault injection: every dealing wavefront sleeps this many times 127 x 64 cycles before it starts
   double score_penalty, mean_reward, reward_refunded, illegal_reward;
   uint64_t game_id0;
   uint4 *state;             // [tiles][chunks][64] live games
@@ -458,7 +460,7 @@ __device__ __forceinline__ void reshuffle_discard(const SkParams &P, uint8_t *lp
 // Returns true when that deal gave itself up (close to a full turn of the generator state, see k_deal): it then left no record and no trace in the stream.
 __device__ __forceinline__ bool wait_deal_done(const SkParams &P, int g) {
   uint32_t f = 0;
-  for (int spin = 0; spin < (1 << 22); spin++) {
+  for (int spin = 0; spin < (1 << P.spin_log2); spin++) {
     f = __hip_atomic_load(&P.done_flag[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((f & 0x7fffffffu) == P.deal_tag) break;
     __builtin_amdgcn_s_sleep(32);
@@ -1899,6 +1901,7 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
     *P.bank_empty = 0;
   }
   if (blockIdx.x * SK_TILE >= count) return;
+  for (uint32_t k = 0; k < P.debug_deal_delay; k++) __builtin_amdgcn_s_sleep(127);  // (fault injection only: 0 in production)
   const int tile = blockIdx.x;  // stamp slot
   (void)tile;
   STAMP_DECL;

@@ -305,6 +305,10 @@ class SkyjoVecEnv:
         _lib.check(self._L.skyjo_vec_set_option(self._h, 2, int(bool(on))))
 
 
+    def set_debug_option(self, option, value):
+        """Fault injection (include/skyjo_vec.h SKYJO_OPT_DEBUG_*): 3 = spin limit (log2), 4 = dealing delay."""
+        _lib.check(self._L.skyjo_vec_set_option(self._h, int(option), int(value)))
+
     def reset_counters(self):
         _lib.check(self._L.skyjo_vec_reset_counters(self._h, None))
 

@@ -182,3 +182,32 @@ def test_handle_runs_on_its_device_from_any_thread():
     with pytest.raises(SkyjoNativeError):
         _engine(64, device=torch.cuda.device_count(), **CFG)
     eng.close()
+
+
+def test_step_kernel_gives_up_loudly_when_the_dealing_kernel_never_arrives():
+    """with the dealing kernel on its own stream a step kernel may have to wait for the one deal in flight for a
+    game (bank empty, slot busy).  If that dealing launch does not make progress the wait is bounded and must NOT fall through
+    silently: the kernel raises a sticky device error and skyjo_vec_get_counters fails until the engine is re-seeded.  Forced
+    here by fault injection: every dealing wavefront sleeps ~0.2 s, the spin limit is 2^6 polls, one-player games (25 steps
+    per episode) empty their banks of three inside one long dealing cycle."""
+    import torch
+    from skyjo_rl_amd import SkyjoNativeError
+
+    cfg = dict(CFG, num_players=1)
+    eng = _engine(128, **cfg)
+    eng.set_overlap(True)
+    eng.set_deal_interval(120)
+    eng.seed(None, 2)
+    assert eng.counters()["steps"] == 0          # healthy so far
+    eng.set_debug_option(3, 6)                   # give up after 64 polls
+    eng.set_debug_option(4, 60000)               # each dealing wavefront sleeps 60000 x 8128 cycles ~ 0.2 s
+    eng.rollout(360, policy_seed=1)              # three dealing cycles: the banks run dry while the deals sleep
+    with pytest.raises(SkyjoNativeError, match="gave up waiting for the dealing kernel"):
+        eng.counters()
+    eng.set_debug_option(4, 0)
+    eng.set_debug_option(3, 22)
+    eng.seed(None, 2)                            # a new seeding clears the error
+    eng.rollout(100, policy_seed=1)
+    c = eng.counters()
+    assert c["steps"] > 0 and c["episodes"] > 0
+    eng.close()
