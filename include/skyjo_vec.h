@@ -52,7 +52,6 @@ extern "C" {
 #define SKYJO_ST_ILLEGAL 1   /* action masked out or out of range: TerminateIllegalWrapper semantics */
 #define SKYJO_ST_NOOP_DONE 2 /* game already over and auto_reset off (skyjo.py:316-321) */
 #define SKYJO_ST_RESET 3     /* game was over: a new episode was dealt, the action was ignored */
-#define SKYJO_ST_WAIT 4      /* reserved (never produced: a missing pre-dealt episode is dealt in place) */
 
 /* skyjo_vec_step: a game whose action is SKYJO_ACTION_SKIP is left exactly as it is (no step, no reset; its record is
  * still written) - the single-game views use it to step ONE game of a shared engine (SkyjoGame(engine=, index=)). */

@@ -6,7 +6,7 @@ Public surface:
   SkyjoGame              core-API compatible single-game view (rlskyjo.game.skyjo)
   policy_ra              rlskyjo.models.random_admissible_policy.policy_ra
 """
-from ._lib import (RNG_MT19937, RNG_PHILOX, ST_ILLEGAL, ST_NOOP_DONE, ST_OK, ST_RESET, ST_WAIT,  # noqa: F401
+from ._lib import (RNG_MT19937, RNG_PHILOX, ST_ILLEGAL, ST_NOOP_DONE, ST_OK, ST_RESET,  # noqa: F401
                    SkyjoNativeError)
 from .vec_env import SkyjoVecEnv  # noqa: F401
 from .aec_env import DEFAULT_CONFIG, SimpleSkyjoEnv, env  # noqa: F401

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("SKYJO_LIB") or os.path.join(_HERE, "libskyjo_vec.so")
 
 ABI_VERSION = 2
 MAX_PLAYERS = 12
-ST_OK, ST_ILLEGAL, ST_NOOP_DONE, ST_RESET, ST_WAIT = 0, 1, 2, 3, 4
+ST_OK, ST_ILLEGAL, ST_NOOP_DONE, ST_RESET = 0, 1, 2, 3
 RNG_MT19937, RNG_PHILOX = 0, 1
 ACTION_SKIP = -1000  # SKYJO_ACTION_SKIP: leave this game as it is (skyjo_vec_step)
 PROF_KERNELS = ("k_step", "k_scan", "k_deal", "k_publish")

@@ -11,14 +11,36 @@ from skyjo_rl_amd.rllib_adapter import PettingZooEnvAdapter
 from tests.oracle_engine import OracleEngine
 
 
-def _make(**cfg):
-    return aec_env.SimpleSkyjoEnv(engine=OracleEngine(1, auto_reset=False, **cfg), wrapped=True, **cfg)
+import pytest
+
+
+def _make(factory=OracleEngine, **cfg):
+    return aec_env.SimpleSkyjoEnv(engine=factory(1, auto_reset=False, **cfg), wrapped=True, **cfg)
+
+
+def _hip(*a, **k):
+    from skyjo_rl_amd import SkyjoVecEnv
+    return SkyjoVecEnv(*a, **k)
 
 
 def test_adapter_episode_matches_aec_env():
+    _episode(OracleEngine)
+
+
+@pytest.mark.gpu
+def test_adapter_episode_matches_aec_env_on_hip_engine():
+    _episode(_hip)
+
+
+@pytest.mark.gpu
+def test_adapter_illegal_action_ends_the_episode_on_hip_engine():
+    _illegal(_hip)
+
+
+def _episode(factory):
     cfg = dict(num_players=3, score_penalty=2.0, observe_other_player_indirect=True, mean_reward=1.0, reward_refunded=0.0)
-    ref = _make(**cfg)
-    ad = PettingZooEnvAdapter(_make(**cfg))
+    ref = _make(factory, **cfg)
+    ad = PettingZooEnvAdapter(_make(factory, **cfg))
     ref.seed(7), ad.seed(7)
     ref.reset()
     obs = ad.reset()
@@ -54,8 +76,12 @@ def test_adapter_episode_matches_aec_env():
 
 
 def test_adapter_illegal_action_ends_the_episode():
+    _illegal(OracleEngine)
+
+
+def _illegal(factory):
     cfg = dict(num_players=2, score_penalty=2.0, observe_other_player_indirect=False, mean_reward=1.0, reward_refunded=0.0)
-    ad = PettingZooEnvAdapter(_make(**cfg))
+    ad = PettingZooEnvAdapter(_make(factory, **cfg))
     ad.seed(3)
     (agent, o), = ad.reset().items()
     with warnings.catch_warnings():
