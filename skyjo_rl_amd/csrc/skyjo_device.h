@@ -1,11 +1,16 @@
 // skyjo_device.h - gfx950 device code of the vectorised SkyJo environment.
 //
 // Execution model: one wavefront (64 lanes) owns one TILE of 64 games; lane l owns game l of
-// the tile for the whole launch.  The tile's packed state is streamed HBM -> LDS with coalesced
-// 16-byte-per-lane loads, every data-dependent byte access of the transition (card slots, pile
-// tops, histogram bins) then hits the lane's private LDS bank (skyjo_layout.h), and the tile is
-// streamed back once per launch.  No MFMA: the path is integer / control work bounded by HBM
-// traffic (DESIGN.md has the byte counts).
+// the tile for the whole launch.  The tile's packed state comes HBM -> LDS by LDS-DMA (memory and LDS
+// share one chunk-major layout, skyjo_layout.h), every data-dependent byte access of the transition
+// (card slots, pile tops, histogram bins) then stays inside the lane's private 16-byte columns, and
+// the tile is streamed back once per launch.  No MFMA: the path is integer / control work bounded by
+// HBM traffic (DESIGN.md has the byte counts).  What only one or two lanes of a wavefront ever do at a
+// time - scoring a finished game, re-dealing it - is where the other 62 wait: the scoring is deferred
+// and batched (SK_SCORE_EVERY), the re-deal overlaps its memory round trip with the live lanes' step.
+//
+// Diagnostic builds (tools/dev/): -DSK_STAMPS (section cycle counters), -DSK_EXP_NO_SCORE / _NO_RARE /
+// _NO_DMA / _NO_DRAIN / _REC_WRAP (leave a piece out and time the rest; results are then wrong on purpose).
 //
 // Semantics follow rlskyjo/game/skyjo.py and rlskyjo/environment/skyjo_env.py; each function
 // cites the lines it restates.  Nothing here shares code with oracle/.
@@ -1167,10 +1172,30 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
       const int pieces = P.L.rec_bytes >> 4, stride = sk_stage_stride(P.L.rec_bytes);
       uint8_t *blk = rec_out + ((size_t)it * P.B + (size_t)tile * SK_TILE) * (size_t)P.L.rec_bytes;
       const int live = P.B - tile * SK_TILE;
-      for (int q = lane; q < pieces * SK_TILE; q += SK_TILE) {  // piece q of the tile's block: record q / pieces, piece q % pieces
-        const int r = q / pieces, p = q - r * pieces;
-        const uint4 v = *(const uint4 *)(stg + r * stride + p * 16);
-        if (r < live) __builtin_nontemporal_store((u32x4_t){v.x, v.y, v.z, v.w}, (u32x4_t *)(blk + (size_t)q * 16));
+      // piece q of the tile's block: record q / pieces, piece q % pieces.  Up to four pieces are read back together and
+      // leave behind a wavefront-uniform branch (see the 64-byte records below: one LDS round trip, not one per piece)
+      for (int q0 = lane; q0 < pieces * SK_TILE; q0 += 4 * SK_TILE) {
+        uint4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int q = q0 + j * SK_TILE, r = q / pieces, p = q - r * pieces;
+          if (q < pieces * SK_TILE) v[j] = *(const uint4 *)(stg + r * stride + p * 16);
+        }
+        if (SK_OFTEN(live >= SK_TILE)) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int q = q0 + j * SK_TILE;
+            if (q0 - lane + j * SK_TILE < pieces * SK_TILE)  // (uniform: whole rows of 64 pieces)
+              __builtin_nontemporal_store((u32x4_t){v[j].x, v[j].y, v[j].z, v[j].w}, (u32x4_t *)(blk + (size_t)q * 16));
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int q = q0 + j * SK_TILE, r = q / pieces;
+            if (q < pieces * SK_TILE && r < live)
+              __builtin_nontemporal_store((u32x4_t){v[j].x, v[j].y, v[j].z, v[j].w}, (u32x4_t *)(blk + (size_t)q * 16));
+          }
+        }
       }
     }
     if (INDIRECT && rec_out) {
