@@ -738,7 +738,7 @@ __device__ __forceinline__ int policy_pick(int phase, const ObsRegs &o, uint32_t
 template <bool INDIRECT, int NP, bool TRUSTED>
 __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uint8_t *fp, uint8_t *ap, HdrRegs &h, uint32_t v0,
                                              uint32_t v1, uint32_t v2, int a, int g, LaneCounters &cnt, Stamps &st,
-                                             uint8_t *pendp, int &pend_fin) {
+                                             uint8_t *pendp, int &pend_fin, const uint4 &row_pre) {
   const int N = P.L.N;
   const int phase = h.w0 & 0xff, p = (h.w0 >> 8) & 0xff;
   const int blk = sk_pb(P.L, p), cardb = blk + PB_CARDS, visb = blk + PB_VIS, pb = P.L.off_pile;
@@ -771,7 +771,11 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
     const int role = (h.w1 >> 16) & 1;
     int nd = h.w1 & 0xff;
     const int ns = (h.w1 >> 8) & 0xff;
+#ifndef SK_NO_ROW_PRE
+    const int hidden_p = (int)((row_pre.w >> 16) & 0xffu);
+#else
     const int hidden_p = LB(blk + PB_HIDDEN);
+#endif
     int pile_top = LI(pb + pile_addr(role, nd > 0 ? nd - 1 : 0));
     const int disc_top = LI(pb + pile_addr(role ^ 1, ns > 0 ? ns - 1 : 0));
     const int disc_below = LI(pb + pile_addr(role ^ 1, ns > 1 ? ns - 2 : 0));
@@ -836,7 +840,11 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
   const int hand = (int)(int8_t)(h.w2 >> 24);
   const int reg = ((h.w1 >> 16) & 1) ^ 1;
   int ns = (h.w1 >> 8) & 0xff;
+#ifndef SK_NO_ROW_PRE
+  const uint4 row = row_pre;  // the acting player's cards and his counters: requested before the policy picked
+#else
   const uint4 row = LQ(blk >> 4);  // the acting player's cards and his counters: one read
+#endif
   const uint32_t c0 = row.x, c1 = row.y, c2 = row.z;
   int sum = (int)(int16_t)(row.w & 0xffffu), hid = (int)((row.w >> 16) & 0xffu), refunded = (int)(row.w >> 24);
   // minima over the OTHER players do not change in this turn (skyjo.py:182-183)
@@ -1106,11 +1114,18 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
       if (!over && !skip) {
         const uint32_t v0 = ob.q0, v1 = ob.q1, v2 = ob.q2;  // the acting player's row, read for the previous record
         STAMP(2);
+#ifndef SK_NO_ROW_PRE
+        // the acting player's card chunk (cards, sum, hidden, refunded) is on its way while the policy picks
+        const uint4 row_pre = LQ(sk_pb(P.L, (h.w0 >> 8) & 0xff) >> 4);
+        asm volatile("" ::: "memory");  // (the request stays up here: the compiler would sink it to its first use)
+#else
+        const uint4 row_pre = make_uint4(0u, 0u, 0u, 0u);
+#endif
         if (POLICY) a = policy_pick(h.w0 & 0xff, ob, word);
 #ifndef SK_STAMPS_FINE
         STAMP(3);
 #endif
-        apply_action<INDIRECT, NP, POLICY>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st, pendp, pend_fin);
+        apply_action<INDIRECT, NP, POLICY>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st, pendp, pend_fin, row_pre);
 #ifdef SK_STAMPS_FINE
         STAMP(6);
 #else

@@ -49,7 +49,7 @@ def test_rollout_to_learner_and_back():
     assert all(torch.isfinite(torch.tensor([out[k][j] for k in ("first", "last") for j in ("policy_loss", "vf_loss", "kl")])))
     assert out["last"]["vf_loss"] < out["first"]["vf_loss"]          # the value branch fits the returns
     assert abs(out["last"]["kl"]) < 0.05                             # the clipped policy stays close
-    assert any(float((p - q).abs().max()) > 0 for p, q in zip(model.policy.parameters(), before))
+    assert any(float((p.detach() - q).abs().max()) > 0 for p, q in zip(model.policy.parameters(), before))
 
     pol.close(), val.close()
     pol, val = repack(model)                                          # updated weights back onto the matrix cores
