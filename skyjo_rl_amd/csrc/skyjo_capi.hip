@@ -192,7 +192,8 @@ int start_deals(skyjo_vec *h, hipStream_t s) {
   if ((rc = prof_events(h, 2, &e0, &e1))) return rc;
   // fixed player counts deal from a 150-word strip per lane (one card per dword); the generic kernel needs the tile + ring
   const int inl = h->overlap ? 0 : 1;  // in line: k_deal publishes its own episodes, no k_publish launch
-  const uint32_t lds_compact = SK_TILE * SK_DECK_STRIDE, lds_generic = (uint32_t)(h->lds_tile + 16384);
+  const uint32_t lds_compact = SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE),  // decks + MtChunkStream's staging rows
+                  lds_generic = (uint32_t)(h->lds_tile + 16384);
   switch (h->P.L.N) {
     case 2: hipExtLaunchKernelGGL(k_deal<2>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel, inl); break;
     case 3: hipExtLaunchKernelGGL(k_deal<3>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel, inl); break;
@@ -311,7 +312,7 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     skyjo_vec_destroy(h);
     return rc;
   }
-  if (cfg->rng_mode == SKYJO_RNG_MT19937 && (rc = dalloc(h, &P.mt, h->G * 624, false))) {
+  if (cfg->rng_mode == SKYJO_RNG_MT19937 && (rc = dalloc(h, &P.mt, h->G * 624 + 16, false)  /* + 16: MtChunkStream::issue reads one word beyond a state */)) {
     skyjo_vec_destroy(h);
     return rc;
   }

@@ -1441,14 +1441,19 @@ __device__ __forceinline__ void shuffle_lds(uint8_t *lp, int base, int n, MtStre
 //                      the outputs before its position - and from then on every lane is chunk-aligned.
 //   PhiloxChunkStream  the counter-based session of PhiloxStream, four blocks per refill.
 // ------------------------------------------------------------------------------------------
+#define SK_STG_STRIDE 80  // 64 bytes of chunk + 4 of address + pad: an odd number of 16-byte units, rows spread over the banks
 struct MtChunkStream {
   uint32_t *mt;
   int base, pos, gen, chunks_made;  // outputs R[pos..15] of chunk `base` are unconsumed; next chunk starts at gen
-  uint32_t R[16], o[17], x[16];
-  bool issued;
+  uint32_t R[16], o[17], x[16], xw;
+  static constexpr bool kLockstep = true;  // the refill loops are run by the whole wavefront (see refill)
+  uint32_t *mt0;     // all states; my_off = word offset of this lane's state in it
+  uint32_t my_off;
+  uint8_t *stg;      // the wavefront's staging rows in LDS (SK_STG_STRIDE bytes per lane) for the cooperative store
+  int lane;
   __device__ __forceinline__ static int wrap(int v) { return v >= 624 ? v - 624 : v; }
-  __device__ __forceinline__ void open(uint32_t *mt_, int packed) {
-    mt = mt_, issued = false, chunks_made = 0;
+  __device__ __forceinline__ void open(uint32_t *mt0_, uint32_t my_off_, int packed, uint8_t *stg_, int lane_) {
+    mt0 = mt0_, my_off = my_off_, mt = mt0_ + my_off_, stg = stg_, lane = lane_, chunks_made = 0;
     int idx = packed & 0xffff;
     idx = idx >= 624 ? 0 : idx;
     const int ahead = packed >> 16;  // <= 16: outputs idx .. idx+ahead-1 are already regenerated in memory
@@ -1470,39 +1475,61 @@ struct MtChunkStream {
       o[4 * k] = q.x, o[4 * k + 1] = q.y, o[4 * k + 2] = q.z, o[4 * k + 3] = q.w;
     }
     o[16] = mt[c + 16 == 624 ? 0 : c + 16];
-    if (c != 224) {
-      typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-      const u32x4_a4 *px = (const u32x4_a4 *)(mt + (c < 224 ? c + 397 : c - 227));
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const u32x4_a4 q = px[k];
-        x[4 * k] = q.x, x[4 * k + 1] = q.y, x[4 * k + 2] = q.z, x[4 * k + 3] = q.w;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 16; k++) x[k] = mt[k < 3 ? 621 + k : k - 3];
+    // The partners i + 397 (mod 624), without a branch (with the two cases in two exec-masked blocks the compiler merges their
+    // registers behind each block and waits for the loads right there, a few instructions after they were issued).  Chunk 224 is the one whose partners wrap (621, 622, 623,
+    // 0 .. 12): its pieces 1 .. 3 are words 1 .. 12 = (224 - 227) + 4 k like every chunk above it, piece 0 is read at 621
+    // (three partners and one word beyond the state: the allocation has the slack) and word 0 comes with a one-word
+    // load that every other chunk points at a line it is requesting anyway.
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    const uint32_t *pb = mt + (c < 224 ? c + 397 : c - 227);
+    const u32x4_a4 *p0 = (const u32x4_a4 *)(c == 224 ? mt + 621 : pb);
+    {
+      const u32x4_a4 q = *p0;
+      x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
     }
-    issued = true;
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+      const u32x4_a4 q = ((const u32x4_a4 *)pb)[k];
+      x[4 * k] = q.x, x[4 * k + 1] = q.y, x[4 * k + 2] = q.z, x[4 * k + 3] = q.w;
+    }
+    xw = mt[c == 224 ? 0 : c];
   }
-  __device__ __forceinline__ void pre_loop() {  // the lane is about to run out of outputs: start the next chunk's loads
-    if (!issued) issue();
-  }
-  // Regenerate chunk `gen` in place (its loads were started a chunk earlier) and start the loads of the chunk
-  // after it.  Those loads go out BEFORE this chunk's stores: vmcnt counts in order, so a wait for loads that
-  // were issued behind stores would also wait for the stores' round trip to memory.
-  __device__ __forceinline__ void refill() {
+  __device__ __forceinline__ void pre_loop() { issue(); }  // the first chunk's loads (once per deal, every lane)
+  // Regenerate chunk `gen` in place (its loads were started a chunk earlier), write it back and start the loads of
+  // the chunk after it.
+  //
+  // The dealing kernel is bound by the memory system (5.3 TB/s of 128-byte line reads and 64-byte write-backs at the
+  // fabric), and most sensitive to how the state is WRITTEN: stored by its owner, a chunk is four
+  // 16-byte pieces in four instructions, each of which scatters 64 pieces over 64 lines.  So the wavefront writes
+  // TOGETHER: every lane puts its chunk and its address into its staging row in LDS, and store instruction k is lane i
+  // writing piece i & 3 of the lane 16 k + (i >> 2) - four neighbouring lanes one whole 64-byte line, a quarter of the
+  // write requests.  That takes all 64 lanes: the refill loops are run by the whole wavefront until its last lane is
+  // through, and a lane that is (`live` false) keeps its stream where it is and stores nothing.  The stores go out
+  // BEFORE the next chunk's loads (the other order: 81 instead of 76 us per run).
+  __device__ __forceinline__ void refill(const bool live) {
     const int c = gen;
     uint32_t v[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = mt_twist3(o[k], o[k + 1], x[k]);
-    base = c, pos = 0, chunks_made++;
-    gen = c + 16 == 624 ? 0 : c + 16;
-    issue();
+    for (int k = 0; k < 16; k++) v[k] = mt_twist3(o[k], o[k + 1], k == 3 && c == 224 ? xw : x[k]);
+    base = live ? c : base, pos = live ? 0 : pos, chunks_made += live ? 1 : 0;
+    gen = live ? (c + 16 == 624 ? 0 : c + 16) : c;
+    const uint32_t lm = live ? 0xffffffffu : 0u;  // (a select the compiler cannot turn into a branch around the tempering)
 #pragma unroll
-    for (int k = 0; k < 16; k++) R[k] = mt_temper3(v[k]);
-    uint4 *pm = (uint4 *)(mt + c);
+    for (int k = 0; k < 16; k++) R[k] = __builtin_amdgcn_bitop3_b32(R[k], mt_temper3(v[k]), lm, 0xd8);
+    uint8_t *row = stg + lane * SK_STG_STRIDE;
 #pragma unroll
-    for (int k = 0; k < 4; k++) pm[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    for (int k = 0; k < 4; k++) ((uint4 *)row)[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    *(uint32_t *)(row + 64) = live ? my_off + (uint32_t)c : 0xffffffffu;
+    __builtin_amdgcn_wave_barrier();  // (LDS runs a wavefront's accesses in order: no wait, only no reordering by the compiler)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint8_t *orow = stg + (16 * k + (lane >> 2)) * SK_STG_STRIDE;
+      const uint4 q = *(const uint4 *)(orow + (lane & 3) * 16);
+      const uint32_t off = *(const uint32_t *)(orow + 64);
+      if (off != 0xffffffffu) *(uint4 *)(mt0 + off + 4 * (lane & 3)) = q;
+    }
+    __builtin_amdgcn_wave_barrier();
+    issue();  // (a lane that is through asks for the same chunk again)
   }
 };
 
@@ -1512,8 +1539,9 @@ struct PhiloxChunkStream {  // same output sequence as PhiloxStream (block b -> 
   __device__ __forceinline__ void open(uint64_t key, uint32_t episode, uint32_t resh, uint32_t domain) {
     k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32), blk = 0, c1 = episode, c2 = resh, c3 = domain, pos = 16;
   }
+  static constexpr bool kLockstep = false;
   __device__ __forceinline__ void pre_loop() {}
-  __device__ __forceinline__ void refill() {
+  __device__ __forceinline__ void refill(bool) {
 #pragma unroll
     for (int b = 0; b < 4; b++) philox4x32_10(blk + b, c1, c2, c3, k0, k1, R[4 * b], R[4 * b + 1], R[4 * b + 2], R[4 * b + 3]);
     blk += 4, pos = 0;
@@ -1622,7 +1650,7 @@ __device__ __forceinline__ void perm_batch(Rng &r, const int s, PermWalk &w) {
 // RNG order: shuffle(150) -> shuffle(rest) -> NP x permutation(12)[:2].
 template <int NP, class Rng>
 __device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_raw_base, const int lane, Rng &r, uint32_t episode,
-                                             uint4 *dst) {
+                                             uint4 *dst, const bool act) {
   constexpr int R = SK_NCARDS - 12 * NP;
   const SkLayout L = sk_make_layout(NP, P.L.indirect);
   const uint32_t dk = (uint32_t)lane * SK_DECK_STRIDE;  // LDS address of the lane's card 0
@@ -1635,18 +1663,21 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_ra
       if (4 * d + j < SK_NCARDS) w4 |= (uint32_t)((-2 + (4 * d + j) / 10) & 0xff) << (8 * j);
     DK_AT32(dk + 4 * d) = w4;
   }
+  // A lockstep stream (MtChunkStream) has every lane of the wavefront in the refill loops, also the lanes without a deal
+  // (act false: they walk nothing, n = 0 from the start) and the lanes that are through: see MtChunkStream::refill.
+#define SK_WALKING(n) (Rng::kLockstep ? __any((n) != 0u) : (n) != 0u)
   {
     DeckWalk w;
-    w.pb = dk, w.pcur = dk + (SK_NCARDS - 1), w.n = SK_NCARDS, w.nxt_n = R, w.mask = 0xffu;
+    w.pb = dk, w.pcur = dk + (SK_NCARDS - 1), w.n = act ? SK_NCARDS : 0u, w.nxt_n = R, w.mask = 0xffu;
     if (r.pos < 16) {
 #define SK_CALL(s) deck_batch<true, NP>(r, s, lds_raw_base, dk, w);
       SK_DECK_BATCHES(SK_CALL)
 #undef SK_CALL
       r.pos = w.n ? 16 : r.pos;
     }
-    if (w.n) r.pre_loop();
-    while (w.n) {
-      r.refill();
+    if (SK_WALKING(w.n)) r.pre_loop();
+    while (SK_WALKING(w.n)) {
+      r.refill(w.n != 0u);
 #define SK_CALL(s) deck_batch<false, NP>(r, s, lds_raw_base, dk, w);
       SK_DECK_BATCHES(SK_CALL)
 #undef SK_CALL
@@ -1654,7 +1685,7 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_ra
     }
   }
   PermWalk pw;
-  pw.pm = 0xBA9876543210ull, pw.n = 12u, pw.mask = 0xfu, pw.sh = 0u, pw.open = 0u;
+  pw.pm = 0xBA9876543210ull, pw.n = act ? 12u : 0u, pw.mask = 0xfu, pw.sh = 0u, pw.open = 0u;
   {
     if (r.pos < 16) {
 #define SK_CALL(s) perm_batch<true, NP>(r, s, pw);
@@ -1662,15 +1693,16 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_ra
 #undef SK_CALL
       r.pos = pw.n ? 16 : r.pos;
     }
-    if (pw.n) r.pre_loop();
-    while (pw.n) {
-      r.refill();
+    while (SK_WALKING(pw.n)) {  // (the next chunk's loads are in flight since the deck's last refill)
+      r.refill(pw.n != 0u);
 #define SK_CALL(s) perm_batch<false, NP>(r, s, pw);
       SK_FOUR_BATCHES(SK_CALL)
 #undef SK_CALL
       r.pos = pw.n ? 16 : r.pos;
     }
   }
+#undef SK_WALKING
+  if (!act) return;
   // ---- assemble the record (skyjo_layout.h) in registers ----
   uint32_t rec[20 * 4];
   const int nwords = L.chunks * 4;
@@ -1958,28 +1990,29 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
     // The stream advances in place; the position it had before this deal is kept with the slot so that a mid-game
     // reshuffle of the live episode (which numpy would have drawn BEFORE this deal) can step the stream back
     // (mt_untwist) and have the deal redone (reshuffle_dispatch).
+    // (the lanes without a deal go through the compact deal too, walking nothing: MtChunkStream::refill needs the whole wavefront)
+    const int packed = P.mt_idx[g];
+    if (act) P.mt_idx[(size_t)(1 + slot) * G + g] = packed;
+    int generated = 0;
+    if (NP > 0) {
+      MtChunkStream r;
+      r.open(P.mt, (uint32_t)g * 624u, packed, (uint8_t *)lds_raw + SK_TILE * SK_DECK_STRIDE, lane);
+      STAMP(2);
+      deal_compact<NP>(P, lds_raw, lane, r, ep, dst, act);
+      if (act) P.mt_idx[g] = r.close();
+      generated = r.chunks_made * 16;
+    } else if (act) {
+      uint8_t *fp = (uint8_t *)lds_raw + P.L.chunks * 1024 + lane * 4;
+      MtStream<64> r;
+      r.open(P.mt + (size_t)g * 624, packed, fp);
+      r.stp = &st;
+      STAMP(2);
+      deal_into_lds(P, lp, r, ep);
+      P.mt_idx[g] = r.close();
+      generated = r.wp - (((16 - ((packed >> 16) & 15)) & 15) + (packed >> 16));
+    }
     if (act) {
       uint32_t *mt = P.mt + (size_t)g * 624;
-      const int packed = P.mt_idx[g];
-      P.mt_idx[(size_t)(1 + slot) * G + g] = packed;
-      int generated;
-      if (NP > 0) {
-        MtChunkStream r;
-        r.open(mt, packed);
-        STAMP(2);
-        deal_compact<NP>(P, lds_raw, lane, r, ep, dst);
-        P.mt_idx[g] = r.close();
-        generated = r.chunks_made * 16;
-      } else {
-        uint8_t *fp = (uint8_t *)lds_raw + P.L.chunks * 1024 + lane * 4;
-        MtStream<64> r;
-        r.open(mt, packed, fp);
-        r.stp = &st;
-        STAMP(2);
-        deal_into_lds(P, lp, r, ep);
-        P.mt_idx[g] = r.close();
-        generated = r.wp - (((16 - ((packed >> 16) & 15)) & 15) + (packed >> 16));
-      }
       mt_overrun = generated > 624 - 64;  // close to a full turn of the state: positions alone could no longer tell
       if (mt_overrun) {                   // how far a rollback has to go, so give this speculation up right here
         int k0 = (packed & 0xffff) + (packed >> 16);
@@ -1995,7 +2028,7 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
     if (NP > 0) {
       PhiloxChunkStream r;
       r.open(P.seeds[g] + 1, ep, 0u, 0u);
-      deal_compact<NP>(P, lds_raw, lane, r, ep, dst);
+      deal_compact<NP>(P, lds_raw, lane, r, ep, dst, true);
     } else {
       PhiloxStream r;
       r.open(P.seeds[g] + 1, ep, 0u, 0u);

@@ -1,0 +1,1 @@
+timeout -k 10 600 python tools/dev/ab.py build_exp/coop.so build_exp/coop_sf.so build_exp/coop_xnt.so
