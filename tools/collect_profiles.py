@@ -29,7 +29,7 @@ digest.append({"note": "same run, bench.py's own HIP-event figure for the last 3
 json.dump(digest, open(os.path.join(dst, "r2_kernel_trace_digest.json"), "w"), indent=1)
 # PMC passes
 pmc = {}
-for tag in ("fetch", "write", "sq", "sq2"):
+for tag in ("fetch", "write", "sq", "sq2", "ea", "l2"):
     f = find("pmc_%s/**/*counter_collection.csv" % tag)
     if not f:
         continue
@@ -52,6 +52,14 @@ traffic = {
     "uncorrected_bytes_per_launch": int(round((fk + wk) * 1024)),
     "k_deal_bytes_per_launch_uncorrected": int(round((pmc["fetch"][kd]["FETCH_SIZE"] + pmc["write"][kd]["WRITE_SIZE"]) * 1024)),
 }
+if "ea" in pmc:  # the dealing kernel at the fabric: read requests by size (nearly all 128-byte lines), write requests (64-byte and smaller)
+    e = pmc["ea"][kd]
+    rd128, rd, wr64, wr = e["TCC_EA0_RDREQ_128B_sum"], e["TCC_EA0_RDREQ_sum"], e["TCC_EA0_WRREQ_64B_sum"], e["TCC_EA0_WRREQ_sum"]
+    traffic["k_deal_fabric"] = {
+        "read_requests": rd, "read_requests_128B": rd128, "write_requests": wr, "write_requests_64B": wr64,
+        "read_bytes": int(rd128 * 128 + (rd - rd128) * 64), "write_bytes": int(wr64 * 64 + (wr - wr64) * 32),
+        "note": "per dealing run (k_deal dispatch): TCC_EA0_RDREQ[_128B] / TCC_EA0_WRREQ[_64B]; reads that are not 128-byte "
+                "requests counted as 64 bytes, writes that are not 64-byte requests as 32 bytes"}
 json.dump(traffic, open(os.path.join(dst, "r2_hbm_traffic.json"), "w"), indent=1)
 # config 5
 c5 = os.path.join(src, "cfg5.json")
