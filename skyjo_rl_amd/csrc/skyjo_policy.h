@@ -42,14 +42,29 @@ struct SkMlpDev {
   int out_dim;
 };
 
-__device__ __forceinline__ float skp_tanh(float x) {
-  const float t = __expf(2.0f * x);  // inf for large x -> 1, 0 for very negative x -> -1
-  return 1.0f - 2.0f / (t + 1.0f);
+// tanh(x) = 1 - 2 / (e^(2x) + 1) on two values at a time: the multiply, the add and the final multiply-add are packed
+// fp32 instructions (v_pk_*_f32, two values per issue slot), the exponential and the reciprocal are the hardware's
+// approximations (v_exp_f32, v_rcp_f32: 1 ulp - the result is rounded to bf16 anyway).  An IEEE division here
+// (v_div_scale x 2, v_rcp, four v_fma, v_div_fmas, v_div_fixup per value) made the activation 13 instructions per
+// value and the whole kernel a third slower.  e^(2x) = inf for large x -> 1, 0 for very negative x -> -1.
+typedef float skp_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ skp_f32x2 skp_tanh2(skp_f32x2 x) {
+  const skp_f32x2 y = x * 2.8853900817779268f;  // 2 / ln 2
+  skp_f32x2 t;
+  t.x = __builtin_amdgcn_exp2f(y.x), t.y = __builtin_amdgcn_exp2f(y.y);
+  t = t + 1.0f;
+  skp_f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(t.x), r.y = __builtin_amdgcn_rcpf(t.y);
+  return __builtin_elementwise_fma(r, (skp_f32x2){-2.0f, -2.0f}, (skp_f32x2){1.0f, 1.0f});
 }
 __device__ __forceinline__ skp_bf16x8 skp_pack8(const skp_f32x16 &a, int s, bool act) {
   skp_bf16x8 r;
 #pragma unroll
-  for (int j = 0; j < 8; j++) r[j] = (__bf16)(act ? skp_tanh(a[8 * s + j]) : a[8 * s + j]);
+  for (int j = 0; j < 8; j += 2) {
+    skp_f32x2 v = {a[8 * s + j], a[8 * s + j + 1]};
+    if (act) v = skp_tanh2(v);
+    r[j] = (__bf16)v.x, r[j + 1] = (__bf16)v.y;
+  }
   return r;
 }
 __device__ __forceinline__ skp_bf16x8 skp_frag(const uint4 *p) {
@@ -65,7 +80,7 @@ __device__ __forceinline__ skp_bf16x8 skp_frag(const uint4 *p) {
 #define SKP_GT 1  // (2: 47.7 us vs 42.7 us per 65 536 records - the kernel is bound by its 512 tanh per game, not by weight traffic)
 // A launch may carry TWO nets over the same records (grid.y = 2): workgroups with blockIdx.y == 1 evaluate `net_b` into
 // `out_b` (no draw) - the policy and the value branch of the action-mask model in one launch (skyjo_vec_mlp_act_value).
-__global__ __launch_bounds__(64) void k_mlp_forward(SkMlpDev net_a, const uint8_t *rec, int rec_bytes, int obs_dim, long long n,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mlp_forward(SkMlpDev net_a, const uint8_t *rec, int rec_bytes, int obs_dim, long long n,
                                                      float *out_a, SkMlpDraw draw_a, SkMlpDev net_b, float *out_b) {
   const bool second = blockIdx.y == 1;
   const SkMlpDev net = second ? net_b : net_a;
