@@ -235,7 +235,8 @@ def main():
                                    if record else f"{B} x {N}-player games per GPU, no records",
                        "games_per_gpu": B, "num_players": N, "rng_mode": args.rng,
                        "iterations_per_step": CHUNK, "timed_iterations": args.steps * CHUNK, "warmup_iterations": args.warmup * CHUNK,
-                       "dealing": "beside k_step (own stream)" if eng.overlap() else "in line",
+                       "dealing": "beside k_step (own stream; k_scan lists the banks to fill)" if eng.overlap() else
+                                  ("in line (k_scan + k_deal)" if os.environ.get("SKYJO_FUSED_SCAN") == "0" else "in line (k_deal scans the banks itself)"),
                        "shared_gpu_rehearsal": shared_gpu,
                        "parallelism": f"games sharded over {world} GPU(s) by global game id, no data-path collective; one all-gather of the statistics record"},
             "ms_per_iteration": wall_ms / CHUNK,

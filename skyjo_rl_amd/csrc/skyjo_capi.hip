@@ -82,6 +82,7 @@ struct skyjo_vec {
   uint32_t *health_host = nullptr;
   // dealing pipeline: k_scan / k_publish on the caller's stream, k_deal on deal_stream when overlap is on
   bool overlap = true;
+  bool fused_scan = true;  // in line: k_deal looks at the banks itself (SKYJO_FUSED_SCAN=0: diagnostic, the k_scan + work list form)
   hipStream_t deal_stream = nullptr;
   hipEvent_t ev_scan = nullptr, ev_dealt = nullptr;
   bool deal_inflight = false;
@@ -179,10 +180,15 @@ int start_deals(skyjo_vec *h, hipStream_t s) {
   h->P.deal_tag = h->deal_tag;
   // (the list's counter was cleared by the previous run's publish step)
   hipEvent_t e0, e1;
-  if ((rc = prof_events(h, 1, &e0, &e1))) return rc;
-  hipExtLaunchKernelGGL(k_scan, dim3((h->P.B + SK_SCAN_BLOCK - 1) / SK_SCAN_BLOCK), dim3(SK_SCAN_BLOCK), 0, s, e0, e1, 0, h->P,
-                        h->list_sel);
-  HIPCHK(hipGetLastError());
+  // In line, the dealing kernel looks at the banks itself (lane = game): no k_scan launch, no work list.  Beside the step
+  // kernel the list is made here, on the caller's stream, where it is ordered with the step launches around it.
+  const bool fused = !h->overlap && h->fused_scan;
+  if (!fused) {
+    if ((rc = prof_events(h, 1, &e0, &e1))) return rc;
+    hipExtLaunchKernelGGL(k_scan, dim3((h->P.B + SK_SCAN_BLOCK - 1) / SK_SCAN_BLOCK), dim3(SK_SCAN_BLOCK), 0, s, e0, e1, 0, h->P,
+                          h->list_sel);
+    HIPCHK(hipGetLastError());
+  }
   hipStream_t ds = s;
   if (h->overlap) {
     HIPCHK(hipEventRecord(h->ev_scan, s));
@@ -191,7 +197,7 @@ int start_deals(skyjo_vec *h, hipStream_t s) {
   }
   if ((rc = prof_events(h, 2, &e0, &e1))) return rc;
   // fixed player counts deal from a 150-word strip per lane (one card per dword); the generic kernel needs the tile + ring
-  const int inl = h->overlap ? 0 : 1;  // in line: k_deal publishes its own episodes, no k_publish launch
+  const int inl = h->overlap ? 0 : (fused ? 2 : 1);  // in line: k_deal publishes its own episodes, no k_publish launch
   const uint32_t lds_compact = SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE),  // decks + MtChunkStream's staging rows
                   lds_generic = (uint32_t)(h->lds_tile + 16384);
   switch (h->P.L.N) {
@@ -303,7 +309,7 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
       (rc = dalloc(h, &P.spare_ready, SK_BANK * h->G)) || (rc = dalloc(h, &P.bank_head, h->G)) ||
       (rc = dalloc(h, &P.busy, h->G)) || (rc = dalloc(h, &P.cancel, h->G)) || (rc = dalloc(h, &P.done_flag, h->G)) ||
       (rc = dalloc(h, &P.deal_list, 2 * h->G)) || (rc = dalloc(h, &P.deal_ep, 2 * h->G)) ||
-      (rc = dalloc(h, &P.deal_count, 2)) || (rc = dalloc(h, &P.bank_empty, 1)) ||
+      (rc = dalloc(h, &P.deal_count, 2)) || (rc = dalloc(h, &P.bank_empty, 2)) ||
       (rc = dalloc(h, &P.mt_idx, (1 + SK_BANK) * h->G)) || (rc = dalloc(h, &P.seeds, h->G)) ||
       (rc = dalloc(h, &P.deals_consumed, h->G)) || (rc = dalloc(h, &P.rewards, h->G * N)) ||
       (rc = dalloc(h, &P.scores, h->G * N)) || (rc = dalloc(h, &P.done, h->G)) ||
@@ -340,6 +346,7 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   // k_deal beside it), so there it runs in line.  SKYJO_OPT_OVERLAP / SKYJO_OVERLAP override.
   h->overlap = P.tiles <= 640;
   if (const char *e = getenv("SKYJO_OVERLAP")) h->overlap = atoi(e) != 0;
+  if (const char *e = getenv("SKYJO_FUSED_SCAN")) h->fused_scan = atoi(e) != 0;
   h->deal_every_iters = h->interval_default = deal_interval_default(cfg->num_players, h->overlap);
   if (const char *e = getenv("SKYJO_DEAL_INTERVAL")) {
     const int v = atoi(e);

@@ -64,7 +64,7 @@ struct SkParams {
   int32_t *deal_list;       // [2][tiles*64] games of the current / previous dealing launch (k_scan)
   uint32_t *deal_ep;        // [2][tiles*64] episode index of each listed deal
   uint32_t *deal_count;     // [2]
-  uint32_t *bank_empty;     // [1] games whose bank held no episode when the last k_scan looked (early warning of a drain)
+  uint32_t *bank_empty;     // [2] games whose bank held no episode when the last scan looked (early warning of a drain); [1]: see k_deal
   volatile uint32_t *health_host;  // [2] host-mapped: {that count, dealing-run tag} - written once per run, read by the host
   uint32_t *mt;             // [tiles*64][624] numpy-legacy MT19937 state, advanced in place (mt_untwist steps it back)
   int32_t *mt_idx;          // [1+SK_BANK][tiles*64]: [0] stream position (idx | ahead << 16), [1 + slot] position before its deal
@@ -1967,23 +1967,58 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
   const size_t G = (size_t)P.tiles * SK_TILE;
   const int count = (int)P.deal_count[list_sel];
   const int i = blockIdx.x * SK_TILE + lane;
+  // publish_inline == 2: in line AND its own scan - lane = game, every lane looks at its game's bank itself (what k_scan
+  // does, minus the work list: no launch in front of this one; the lanes whose bank is full idle through the refill loops)
+  const bool fused = publish_inline == 2;
   if (publish_inline && blockIdx.x == 0 && lane == 0) {
     P.deal_count[list_sel ^ 1] = 0;  // for the next run's k_scan
-    P.health_host[0] = *P.bank_empty, P.health_host[1] = P.deal_tag;  // (host-mapped memory: the host adapts the dealing interval)
-    *P.bank_empty = 0;
+    // (host-mapped memory: the host adapts the dealing interval.)  Fused, this run's count of empty banks is still being
+    // added up by the other wavefronts: the previous run's goes out, each run counts into the word of its list_sel.
+    uint32_t *be = P.bank_empty + (fused ? (list_sel ^ 1) & 1 : 0);
+    P.health_host[0] = *be, P.health_host[1] = P.deal_tag;
+    *be = 0;
   }
-  if (blockIdx.x * SK_TILE >= count) return;
+  if (!fused && blockIdx.x * SK_TILE >= count) return;
   for (uint32_t k = 0; k < P.debug_deal_delay; k++) __builtin_amdgcn_s_sleep(127);  // (fault injection only: 0 in production)
   const int tile = blockIdx.x;  // stamp slot
   (void)tile;
   STAMP_DECL;
   STAMP(0);
-  const bool listed = i < count;
-  const int g = listed ? P.deal_list[(size_t)list_sel * G + i] : 0;
-  const uint32_t ep = listed ? P.deal_ep[(size_t)list_sel * G + i] : 0u;
-  const int owner = listed ? P.busy[g] : 0;
-  const bool act = owner > 0;  // (an entry whose game is not marked busy would be a stale list: never dealt)
-  const int slot = act ? owner - 1 : 0;
+  int g, slot;
+  uint32_t ep;
+  bool act;
+  if (fused) {
+    const bool listed = i < P.B;
+    g = listed ? i : 0;
+    const uint8_t busy = P.busy[g];
+    const int head = P.bank_head[g] % SK_BANK;
+    const uint32_t consumed = P.deals_consumed[g];
+    uint8_t ready[SK_BANK];
+#pragma unroll
+    for (int k = 0; k < SK_BANK; k++) ready[k] = P.spare_ready[(size_t)k * G + g];
+    bool open = true;
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < SK_BANK; k++) {  // r = number of ready slots in stream order from `head` (as in k_scan)
+      uint8_t f = 0;
+#pragma unroll
+      for (int j = 0; j < SK_BANK; j++) f = (head + k) % SK_BANK == j ? ready[j] : f;
+      open = open && f != 0;
+      r += open ? 1 : 0;
+    }
+    act = listed && !busy && r < SK_BANK;
+    slot = (head + r) % SK_BANK;
+    ep = consumed + (uint32_t)r;
+    const unsigned long long be = __ballot(act && r == 0);
+    if (be && lane == 0) atomicAdd(P.bank_empty + (list_sel & 1), (uint32_t)__popcll(be));  // (rare)
+  } else {
+    const bool listed = i < count;
+    g = listed ? P.deal_list[(size_t)list_sel * G + i] : 0;
+    ep = listed ? P.deal_ep[(size_t)list_sel * G + i] : 0u;
+    const int owner = listed ? P.busy[g] : 0;
+    act = owner > 0;  // (an entry whose game is not marked busy would be a stale list: never dealt)
+    slot = act ? owner - 1 : 0;
+  }
   uint4 *dst = P.spare + ((size_t)slot * P.tiles + g / SK_TILE) * P.L.chunks * SK_TILE + g % SK_TILE;
   bool mt_overrun = false;
   if (P.rng_mode == SKYJO_RNG_MT19937) {
@@ -1996,7 +2031,8 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
     int generated = 0;
     if (NP > 0) {
       MtChunkStream r;
-      r.open(P.mt, (uint32_t)g * 624u, packed, (uint8_t *)lds_raw + SK_TILE * SK_DECK_STRIDE, lane);
+      // (a lane without a deal loads along - from the very first state, whose lines every such lane of the chip asks for)
+      r.open(P.mt, act ? (uint32_t)g * 624u : 0u, packed, (uint8_t *)lds_raw + SK_TILE * SK_DECK_STRIDE, lane);
       STAMP(2);
       deal_compact<NP>(P, lds_raw, lane, r, ep, dst, act);
       if (act) P.mt_idx[g] = r.close();

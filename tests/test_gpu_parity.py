@@ -240,6 +240,14 @@ def test_deal_cadence_does_not_change_results(N, rng_mode, interval, overlap):
     eng.close()
 
 
+@pytest.mark.parametrize("N,rng_mode,interval", [(3, 0, 16), (2, 0, 1000), (12, 0, 8), (8, 1, 16)])
+def test_inline_dealing_with_work_list_form(N, rng_mode, interval, monkeypatch):
+    """In line the dealing kernel scans the banks itself (lane = game); SKYJO_FUSED_SCAN=0 selects the k_scan + work list
+    form the dealing run beside the step kernel uses, here in line: same results."""
+    monkeypatch.setenv("SKYJO_FUSED_SCAN", "0")
+    test_deal_cadence_does_not_change_results(N, rng_mode, interval, False)
+
+
 def test_headline_size_properties():
     """BASELINE config 3 (65 536 three-player games): size-independent invariants + an oracle-checked subset."""
     import torch
