@@ -216,7 +216,7 @@ int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
 #define SKYJO_OPT_DEAL_INTERVAL 1
 /* SKYJO_OPT_OVERLAP: 1 = the dealing kernel runs on a stream of its own beside the step kernels that follow it
  * (its episodes are published one dealing cycle later), 0 = it runs in line on the caller's stream.  Default: 1 when
- * the batch leaves SIMDs idle (at most 640 tiles of 64 games), 0 on a full chip; environment override SKYJO_OVERLAP.
+ * the batch leaves SIMDs idle (at most 768 tiles of 64 games), 0 on a full chip; environment override SKYJO_OVERLAP.
  * Results do not depend on this setting. */
 #define SKYJO_OPT_OVERLAP 2
 /* Fault injection for the tests (never needed in production): SKYJO_OPT_DEBUG_SPIN_LOG2 - a step kernel that has to wait

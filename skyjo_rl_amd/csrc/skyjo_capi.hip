@@ -340,11 +340,11 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     h->health_host[0] = h->health_host[1] = 0;
     P.health_host = (volatile uint32_t *)dp;
   }
-  // The dealing kernel runs beside the step kernel (own stream) when the batch leaves SIMDs free: up to 640 tiles of
-  // the 1024 one-wavefront-per-SIMD slots (32 768 three-player games: 14.4 vs 11.7 x 10^9 steps/s).  On a full chip
-  // the two kernels compete for the same vector ALUs and sharing buys 1 % (65 536 games: k_step 155 -> 212 us with
-  // k_deal beside it), so there it runs in line.  SKYJO_OPT_OVERLAP / SKYJO_OVERLAP override.
-  h->overlap = P.tiles <= 640;
+  // The dealing kernel runs beside the step kernel (own stream) when the batch leaves SIMDs free: up to 768 tiles of
+  // the 1024 one-wavefront-per-SIMD slots (three-player games, beside / in line, x 10^9 steps/s: 32 768: 17.1 / 15.5,
+  // 49 152: 23.1 / 22.6, 57 344: 25.2 / 26.1, 65 536: 20.3 / 29.0 - on a full chip the two kernels compete for the same
+  // vector ALUs), in line above that.  SKYJO_OPT_OVERLAP / SKYJO_OVERLAP override.
+  h->overlap = P.tiles <= 768;
   if (const char *e = getenv("SKYJO_OVERLAP")) h->overlap = atoi(e) != 0;
   if (const char *e = getenv("SKYJO_FUSED_SCAN")) h->fused_scan = atoi(e) != 0;
   h->deal_every_iters = h->interval_default = deal_interval_default(cfg->num_players, h->overlap);
