@@ -208,14 +208,15 @@ int skyjo_vec_snapshot_destroy(skyjo_vec_snapshot *snap);
 int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
 
 /* Tunables.  SKYJO_OPT_DEAL_INTERVAL: lockstep iterations (steps or rollout iterations) between two runs of the
- * dealing kernel (1..1024; environment override SKYJO_DEAL_INTERVAL).  Unless it is set, the engine starts at 80 (three
- * and more players) or 64 and adapts: every dealing run reports how many banks it found empty, any empty bank shortens
+ * dealing kernel (1..1024; environment override SKYJO_DEAL_INTERVAL).  Unless it is set, the engine starts at 88 (three
+ * and more players) or 64 - 80 or 56 with the dealing kernel beside the step kernel - and adapts: every dealing run reports how many banks it found empty, any empty bank shortens
  * the interval, a long calm stretch lengthens it again - so it settles below the episode length of the policy in use.  Every game owns a bank of three
  * pre-dealt episodes and a dealing run adds at most one per game; a finished game whose bank is empty deals in
  * place (slow path, same result, counted in skyjo_vec_counters.waits). */
 #define SKYJO_OPT_DEAL_INTERVAL 1
 /* SKYJO_OPT_OVERLAP: 1 = the dealing kernel runs on a stream of its own beside the step kernels that follow it
- * (its episodes are published one dealing cycle later), 0 = it runs in line on the caller's stream.  Default: 1 when
+ * (its episodes are published one dealing cycle later; the step kernel plans and publishes the runs itself, nothing on the
+ * caller's stream waits for the dealing stream), 0 = it runs in line on the caller's stream.  Default: 1 when
  * the batch leaves SIMDs idle (at most 768 tiles of 64 games), 0 on a full chip; environment override SKYJO_OVERLAP.
  * Results do not depend on this setting. */
 #define SKYJO_OPT_OVERLAP 2

@@ -52,9 +52,12 @@ constexpr int kMaxRolloutChunk = 128;  // lockstep iterations per k_step launch 
 // 92 -> 24.9, 96 -> 25.0 x 10^9 steps/s; over 2 x 10^8 episodes 88 and 92 never emptied a bank, 96 did 35 times in
 // 1.2 x 10^8 episodes: 88 it is (0.84 of the mean episode length, like 64 for two players).
 // With the dealing kernel on its own stream a run's episodes arrive one interval later, so the interval is a step
-// shorter there (the runs are hidden behind the step kernel anyway).
-constexpr int deal_interval_default(int num_players, bool overlap) {
-  return overlap ? (num_players >= 3 ? 64 : 48) : (num_players >= 3 ? 88 : 64);
+// shorter there (the runs are hidden behind the step kernel anyway): 64 / 48 with the k_scan + k_publish form, whose
+// caller's stream waits for every run; 80 / 56 in the pipelined form (the default), where a step launch should outlast
+// the dealing kernel beside it (32 768 x 3 players: 64 -> 17.5, 72 -> 19.0, 80 -> 19.4, 88 -> 19.9 x 10^9 steps/s with one
+// bank run dry; 4 096 x 2 players: 48 -> 2.3, 56 -> 2.7, 64 -> 2.9 x 10^9 with twelve).
+constexpr int deal_interval_default(int num_players, bool overlap, bool piped) {
+  return overlap ? (piped ? (num_players >= 3 ? 80 : 56) : (num_players >= 3 ? 64 : 48)) : (num_players >= 3 ? 88 : 64);
 }
 
 }  // namespace
@@ -86,6 +89,8 @@ struct skyjo_vec {
   hipStream_t deal_stream = nullptr;
   hipEvent_t ev_scan = nullptr, ev_dealt = nullptr;
   bool deal_inflight = false;
+  bool piped = true;           // beside the step kernel: the step kernel plans / publishes the runs itself (SKYJO_PIPELINED=0: k_scan + k_publish)
+  bool inflight_piped = false; // the run(s) in flight were planned that way
   int list_sel = 0;
   uint32_t deal_tag = 0;  // k_step launches between two k_deal launches inside skyjo_vec_rollout
   uint64_t iter = 0;        // rollout iterations (the policy's Philox counter)
@@ -142,18 +147,37 @@ int publish_deals(skyjo_vec *h, hipStream_t s) {
   hipEvent_t e0, e1;
   int rc = prof_events(h, 3, &e0, &e1);
   if (rc) return rc;
-  hipExtLaunchKernelGGL(k_publish, dim3(64), dim3(256), 0, s, e0, e1, 0, h->P, h->list_sel);
+  if (h->inflight_piped) {
+    const int G = h->P.tiles * SK_TILE;
+    hipExtLaunchKernelGGL(k_publish_all, dim3((G + 255) / 256), dim3(256), 0, s, e0, e1, 0, h->P);
+  } else {
+    hipExtLaunchKernelGGL(k_publish, dim3(64), dim3(256), 0, s, e0, e1, 0, h->P, h->list_sel);
+  }
   HIPCHK(hipGetLastError());
-  h->deal_inflight = false;
+  h->deal_inflight = false, h->inflight_piped = false;
   return SKYJO_OK;
 }
 
-// One dealing cycle: publish the previous one, list the banks that are not full, deal one episode for each.
-// With overlap on, k_deal runs on its own stream beside the k_step launches that follow; its episodes are
-// published at the start of the next cycle (one dealing interval later), long before a bank of SK_BANK runs dry.
-int start_deals(skyjo_vec *h, hipStream_t s) {
+// mode: 0 = work list, beside the step kernel (k_publish follows); 1 = work list, in line; 2 = in line, lane = game, own
+// scan; 3 = beside the step kernel, lane = game, planned by the step kernel (sk_plan_deals)
+static int launch_deal_kernel(skyjo_vec *h, hipStream_t ds, int mode) {
+  hipEvent_t e0, e1;
   int rc;
-  if ((rc = publish_deals(h, s))) return rc;
+  if ((rc = prof_events(h, 2, &e0, &e1))) return rc;
+  // fixed player counts deal from a byte deck per lane; the generic kernel needs the tile + ring
+  const uint32_t lds_compact = SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE),  // decks + MtChunkStream's staging rows
+                  lds_generic = (uint32_t)(h->lds_tile + 16384);
+  switch (h->P.L.N) {
+    case 2: hipExtLaunchKernelGGL(k_deal<2>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel, mode); break;
+    case 3: hipExtLaunchKernelGGL(k_deal<3>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel, mode); break;
+    case 4: hipExtLaunchKernelGGL(k_deal<4>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel, mode); break;
+    default: hipExtLaunchKernelGGL(k_deal<0>, dim3(h->P.tiles), dim3(SK_TILE), lds_generic, ds, e0, e1, 0, h->P, h->list_sel, mode); break;
+  }
+  HIPCHK(hipGetLastError());
+  return SKYJO_OK;
+}
+
+static void adapt_interval(skyjo_vec *h) {
   if (h->auto_interval) {
     const volatile uint32_t *hh = h->health_host;
     const uint32_t tag = hh[1], empty = hh[0];
@@ -174,10 +198,22 @@ int start_deals(skyjo_vec *h, hipStream_t s) {
       }
     }
   }
-  h->list_sel ^= 1;
+}
+static void next_deal_tag(skyjo_vec *h, bool flip_list) {
+  if (flip_list) h->list_sel ^= 1;  // (the work lists alternate: k_publish of one run clears the other's counter)
   h->deal_tag = (h->deal_tag + 1) & 0x7fffffffu;
   if (h->deal_tag == 0) h->deal_tag = 1;
   h->P.deal_tag = h->deal_tag;
+}
+
+// One dealing cycle: publish the previous one, list the banks that are not full, deal one episode for each.
+// With overlap on, k_deal runs on its own stream beside the k_step launches that follow; its episodes are
+// published at the start of the next cycle (one dealing interval later), long before a bank of SK_BANK runs dry.
+int start_deals(skyjo_vec *h, hipStream_t s) {
+  int rc;
+  if ((rc = publish_deals(h, s))) return rc;
+  adapt_interval(h);
+  next_deal_tag(h, true);
   // (the list's counter was cleared by the previous run's publish step)
   hipEvent_t e0, e1;
   // In line, the dealing kernel looks at the banks itself (lane = game): no k_scan launch, no work list.  Beside the step
@@ -195,21 +231,32 @@ int start_deals(skyjo_vec *h, hipStream_t s) {
     HIPCHK(hipStreamWaitEvent(h->deal_stream, h->ev_scan, 0));
     ds = h->deal_stream;
   }
-  if ((rc = prof_events(h, 2, &e0, &e1))) return rc;
-  // fixed player counts deal from a 150-word strip per lane (one card per dword); the generic kernel needs the tile + ring
   const int inl = h->overlap ? 0 : (fused ? 2 : 1);  // in line: k_deal publishes its own episodes, no k_publish launch
-  const uint32_t lds_compact = SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE),  // decks + MtChunkStream's staging rows
-                  lds_generic = (uint32_t)(h->lds_tile + 16384);
-  switch (h->P.L.N) {
-    case 2: hipExtLaunchKernelGGL(k_deal<2>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel, inl); break;
-    case 3: hipExtLaunchKernelGGL(k_deal<3>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel, inl); break;
-    case 4: hipExtLaunchKernelGGL(k_deal<4>, dim3(h->P.tiles), dim3(SK_TILE), lds_compact, ds, e0, e1, 0, h->P, h->list_sel, inl); break;
-    default: hipExtLaunchKernelGGL(k_deal<0>, dim3(h->P.tiles), dim3(SK_TILE), lds_generic, ds, e0, e1, 0, h->P, h->list_sel, inl); break;
-  }
-  HIPCHK(hipGetLastError());
+  if ((rc = launch_deal_kernel(h, ds, inl))) return rc;
   if (h->overlap) HIPCHK(hipEventRecord(h->ev_dealt, ds));
   h->deal_inflight = h->overlap;
   h->pending_iters = 0;
+  return SKYJO_OK;
+}
+
+// The pipelined form of a dealing cycle beside the step kernel (skyjo_device.h, sk_plan_deals): plan_cycle() before the
+// step launch after which the run is due - that launch plans the run on its way out -, start_deals_piped() after it:
+// the dealing kernel goes to its own stream behind an event for that launch.  Nothing on the caller's stream waits.
+static bool piped_mode(const skyjo_vec *h) { return h->overlap && h->piped; }
+static void plan_cycle(skyjo_vec *h) {
+  next_deal_tag(h, false);
+  h->P.plan_new_tag = h->deal_tag;
+  h->P.ov_flags |= 2u;
+}
+int start_deals_piped(skyjo_vec *h, hipStream_t s) {
+  int rc;
+  HIPCHK(hipEventRecord(h->ev_scan, s));
+  HIPCHK(hipStreamWaitEvent(h->deal_stream, h->ev_scan, 0));
+  if ((rc = launch_deal_kernel(h, h->deal_stream, 3))) return rc;
+  HIPCHK(hipEventRecord(h->ev_dealt, h->deal_stream));
+  h->deal_inflight = true, h->inflight_piped = true;
+  h->pending_iters = 0;
+  adapt_interval(h);  // (for the cycles to come)
   return SKYJO_OK;
 }
 
@@ -220,6 +267,7 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
   int rc;
   hipEvent_t e0, e1;
   if ((rc = prof_events(h, 0, &e0, &e1))) return rc;
+  if (h->deal_inflight && h->inflight_piped) h->P.ov_flags |= 1u;  // publish what has been dealt since (sk_publish_deals)
 #define LAUNCH3(I, Pol, NP)                                                                                       \
   hipExtLaunchKernelGGL((k_step<I, Pol, NP>), grid, block, (uint32_t)h->lds_bytes, s, e0, e1, 0, h->P, actions,   \
                         rec, act_out, iters, policy_seed, h->iter)
@@ -237,6 +285,7 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
 #undef LAUNCH3
 #undef LAUNCH
   HIPCHK(hipGetLastError());
+  h->P.ov_flags = 0;
   h->iters_total += (uint64_t)iters;
   if (policy) h->iter += (uint64_t)iters;  // the policy's Philox counter counts rollout iterations only
   h->pending_iters += iters;
@@ -307,7 +356,7 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   const size_t N = (size_t)cfg->num_players;
   if ((rc = dalloc(h, &P.state, rec16)) || (rc = dalloc(h, &P.spare, SK_BANK * rec16)) ||
       (rc = dalloc(h, &P.spare_ready, SK_BANK * h->G)) || (rc = dalloc(h, &P.bank_head, h->G)) ||
-      (rc = dalloc(h, &P.busy, h->G)) || (rc = dalloc(h, &P.cancel, h->G)) || (rc = dalloc(h, &P.done_flag, h->G)) ||
+      (rc = dalloc(h, &P.busy, h->G)) || (rc = dalloc(h, &P.cancel, h->G)) || (rc = dalloc(h, &P.done_flag, h->G)) || (rc = dalloc(h, &P.plan_tag, h->G)) || (rc = dalloc(h, &P.plan_ep, h->G)) ||
       (rc = dalloc(h, &P.deal_list, 2 * h->G)) || (rc = dalloc(h, &P.deal_ep, 2 * h->G)) ||
       (rc = dalloc(h, &P.deal_count, 2)) || (rc = dalloc(h, &P.bank_empty, 2)) ||
       (rc = dalloc(h, &P.mt_idx, (1 + SK_BANK) * h->G)) || (rc = dalloc(h, &P.seeds, h->G)) ||
@@ -347,7 +396,8 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   h->overlap = P.tiles <= 768;
   if (const char *e = getenv("SKYJO_OVERLAP")) h->overlap = atoi(e) != 0;
   if (const char *e = getenv("SKYJO_FUSED_SCAN")) h->fused_scan = atoi(e) != 0;
-  h->deal_every_iters = h->interval_default = deal_interval_default(cfg->num_players, h->overlap);
+  if (const char *e = getenv("SKYJO_PIPELINED")) h->piped = atoi(e) != 0;
+  h->deal_every_iters = h->interval_default = deal_interval_default(cfg->num_players, h->overlap, h->piped);
   if (const char *e = getenv("SKYJO_DEAL_INTERVAL")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 1024) h->deal_every_iters = v, h->auto_interval = false;
@@ -397,7 +447,7 @@ int skyjo_vec_seed(skyjo_vec *h, const uint64_t *seeds_host, uint64_t base_seed,
   HIPCHK(hipGetLastError());
   int rc;
   // set_seed deals immediately (skyjo.py:88): deal #0 becomes the live game, the following ones fill the bank
-  h->deal_inflight = false;
+  h->deal_inflight = false, h->inflight_piped = false;
   if ((rc = start_deals(h, s)) || (rc = publish_deals(h, s))) return rc;
   h->seeded = true;
   if ((rc = skyjo_vec_reset(h, nullptr, nullptr, stream))) return rc;
@@ -491,7 +541,7 @@ int skyjo_vec_snapshot_restore(skyjo_vec *h, const skyjo_vec_snapshot *sn, void 
   h->list_sel = sn->list_sel, h->auto_interval = sn->auto_interval, h->health_seen = sn->health_seen;
   h->deal_tag = sn->deal_tag, h->P.deal_tag = sn->deal_tag, h->iter = sn->iter, h->iters_total = sn->iters_total;
   h->health_host[0] = sn->health[0], h->health_host[1] = sn->health[1];
-  h->deal_inflight = false;
+  h->deal_inflight = false, h->inflight_piped = false;
   return SKYJO_OK;
 }
 
@@ -531,9 +581,11 @@ int skyjo_vec_step(skyjo_vec *h, const int32_t *actions, void *records_out, void
   GUARD(h);
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   hipStream_t s = (hipStream_t)stream;
+  const bool due = h->pending_iters + 1 >= h->deal_every_iters, piped = piped_mode(h);
+  if (due && piped) plan_cycle(h);
   int rc = launch_step(h, s, false, actions, (uint8_t *)records_out, nullptr, 1, 0);
   if (rc) return rc;
-  if (h->pending_iters >= h->deal_every_iters) return start_deals(h, s);
+  if (due) return piped ? start_deals_piped(h, s) : start_deals(h, s);
   return SKYJO_OK;
 }
 
@@ -549,10 +601,12 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
     // a launch ends where the next dealing run is due, so the cadence does not depend on how the caller slices its calls
     const int due = h->deal_every_iters - h->pending_iters;
     if (n > due) n = due > 0 ? due : 1;
+    const bool run_due = h->pending_iters + n >= h->deal_every_iters, piped = piped_mode(h);
+    if (run_due && piped) plan_cycle(h);
     int rc = launch_step(h, s, true, nullptr, rec, actions_out, n, policy_seed);
     if (rc) return rc;
     done += n;
-    if (h->pending_iters >= h->deal_every_iters && (rc = start_deals(h, s))) return rc;
+    if (run_due && (rc = piped ? start_deals_piped(h, s) : start_deals(h, s))) return rc;
     if (rec) rec += (size_t)n * h->P.B * h->P.L.rec_bytes;
     if (actions_out) actions_out += (size_t)n * h->P.B;
   }
@@ -945,7 +999,7 @@ int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
       if (rc) return rc;
       HIPCHK(hipDeviceSynchronize());
       h->overlap = value != 0;
-      h->interval_default = deal_interval_default(h->P.L.N, h->overlap);
+      h->interval_default = deal_interval_default(h->P.L.N, h->overlap, h->piped);
       if (h->auto_interval) h->deal_every_iters = h->interval_default;
       return SKYJO_OK;
     }

@@ -61,6 +61,10 @@ struct SkParams {
   uint8_t *busy;            // [tiles*64] 0, or 1 + slot while the dealing kernel owns the game's stream and that slot
   uint8_t *cancel;          // [tiles*64] the in-flight deal was overtaken (rolled back or taken early): do not publish
   uint32_t *done_flag;      // [tiles*64] dealing-kernel launch id that last finished a deal for the game
+  uint32_t *plan_tag;       // [tiles*64] id of the dealing launch that deals (dealt) the game's busy slot
+  uint32_t *plan_ep;        // [tiles*64] episode index of that deal (pipelined dealing: see sk_plan_deals)
+  uint32_t ov_flags;        // k_step, dealing beside it: 1 = publish finished deals on the way in, 2 = plan the next run on the way out
+  uint32_t plan_new_tag;    // the id the planned run will have
   int32_t *deal_list;       // [2][tiles*64] games of the current / previous dealing launch (k_scan)
   uint32_t *deal_ep;        // [2][tiles*64] episode index of each listed deal
   uint32_t *deal_count;     // [2]
@@ -465,12 +469,13 @@ __device__ __forceinline__ void reshuffle_discard(const SkParams &P, uint8_t *lp
 // Returns true when that deal gave itself up (close to a full turn of the generator state, see k_deal): it then left no record and no trace in the stream.
 __device__ __forceinline__ bool wait_deal_done(const SkParams &P, int g) {
   uint32_t f = 0;
+  const uint32_t tag = P.plan_tag[g];  // the run that owns the game's busy slot (written on this stream, before this kernel or by this lane)
   for (int spin = 0; spin < (1 << P.spin_log2); spin++) {
     f = __hip_atomic_load(&P.done_flag[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((f & 0x7fffffffu) == P.deal_tag) break;
+    if ((f & 0x7fffffffu) == tag) break;
     __builtin_amdgcn_s_sleep(32);
   }
-  if ((f & 0x7fffffffu) != P.deal_tag) {
+  if ((f & 0x7fffffffu) != tag) {
     // The dealing launch never showed up (it is not resident beside this kernel and this kernel cannot end before it
     // starts): give up loudly.  The sticky word makes skyjo_vec_get_counters fail; results after this point are void.
     atomicOr(P.dev_error, SK_ERR_DEAL_TIMEOUT);
@@ -1052,6 +1057,66 @@ __device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint
 // an immediate and the per-player loops unroll; NP == 0 is the generic kernel for any 1..12 players.
 // SKYJO_ACTION_SKIP as a caller action leaves the game exactly as it is (no step, no reset; its record is still
 // written): that is how the single-game views step ONE game of a shared engine.
+// ------------------------------------------------------------------------------------------
+// Pipelined dealing beside the step kernel (small batches): the step kernel does the bank bookkeeping
+// of its own games itself - lane = game - so that a dealing cycle is ONE launch on the caller's stream and nothing on that
+// stream ever waits for the dealing stream:
+//   on the way out of the launch after which a run is due   sk_plan_deals    what k_scan does, minus the work list: the
+//        slot to fill, its episode index and the run's id go into per-game words, the game is marked busy;
+//   [dealing stream, behind an event for that launch]        k_deal, mode 3   lane = game again: deals the planned slot,
+//        releases its stores and sets done_flag = the run's id;
+//   on the way into every later launch                        sk_publish_deals a busy game whose done_flag carries its
+//        plan's id is acquired and its slot marked ready (what k_publish does).  A deal that is not finished yet
+//        stays busy and is looked at again by the next launch; the rare paths that need a busy game's stream wait
+//        for exactly that deal as before (wait_deal_done).
+// All bank bookkeeping is still written by the caller's stream only, and only by the lane that owns the game.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sk_publish_deals(const SkParams &P, int g) {
+  const size_t G = (size_t)P.tiles * SK_TILE;
+  const int b = P.busy[g];
+  if (b) {
+    const uint32_t tag = P.plan_tag[g];
+    const uint32_t f = __hip_atomic_load(&P.done_flag[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((f & 0x7fffffffu) == tag) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the record the dealing lane released is what a later reset of this game reads
+      if (!P.cancel[g] && f == tag) P.spare_ready[(size_t)(b - 1) * G + g] = 1;  // (bit 31: the deal gave itself up)
+      P.busy[g] = 0, P.cancel[g] = 0;
+    }
+  }
+}
+__device__ __forceinline__ void sk_plan_deals(const SkParams &P, int g) {
+  const size_t G = (size_t)P.tiles * SK_TILE;
+  bool need = false, empty = false;
+  if (g < P.B) {
+    const uint8_t busy = P.busy[g];
+    const int head = P.bank_head[g] % SK_BANK;
+    const uint32_t consumed = P.deals_consumed[g];
+    uint8_t ready[SK_BANK];
+#pragma unroll
+    for (int k = 0; k < SK_BANK; k++) ready[k] = P.spare_ready[(size_t)k * G + g];
+    bool open = true;
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < SK_BANK; k++) {  // r = number of ready slots in stream order from `head` (as in k_scan)
+      uint8_t f = 0;
+#pragma unroll
+      for (int j = 0; j < SK_BANK; j++) f = (head + k) % SK_BANK == j ? ready[j] : f;
+      open = open && f != 0;
+      r += open ? 1 : 0;
+    }
+    need = !busy && r < SK_BANK;
+    empty = need && r == 0;
+    if (need) {
+      P.busy[g] = (uint8_t)(1 + (head + r) % SK_BANK);
+      P.cancel[g] = 0;
+      P.plan_ep[g] = consumed + (uint32_t)r;
+      P.plan_tag[g] = P.plan_new_tag;
+    }
+  }
+  const unsigned long long be = __ballot(empty);
+  if (be && threadIdx.x == 0) atomicAdd(P.bank_empty + (P.plan_new_tag & 1u), (uint32_t)__popcll(be));  // (rare)
+}
+
 template <bool INDIRECT, bool POLICY, int NP>
 __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *actions, uint8_t *rec_out,
                                                   int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0) {
@@ -1079,6 +1144,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
 #endif
   // the tile comes in by LDS-DMA as well (non-temporal: it is read once per launch)
   dma_record<true>((const uint8_t *)P.state, (uint32_t)((((size_t)tile * P.L.chunks) * SK_TILE + lane) * 16), lds_tile, P.L.chunks);
+  if (P.ov_flags & 1u) sk_publish_deals(P, g);  // (while the tile is on its way)
   sk_vm_drain();
   HdrRegs h;
   HDR_LOAD(h);
@@ -1249,6 +1315,17 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   }
   HDR_FLUSH(h);
   tile_store_nt(P, P.state, tile, lane, lp);
+  if (P.ov_flags & 2u) {
+    // (first what the run beside THIS launch has dealt: a game whose busy mark outlived the launch in which it is dealt would
+    // get a new episode only every second run.  The dealing kernel was started before this launch and is as good as through:
+    // a lane whose deal is still under way waits for it - the one place where this stream waits for the other, and only
+    // for as long as the dealing kernel really needs beyond this launch.)
+    if (P.ov_flags & 1u) {
+      if (P.busy[g]) (void)wait_deal_done(P, g);
+      sk_publish_deals(P, g);
+    }
+    sk_plan_deals(P, g);
+  }
   // per-wavefront event counts go to the tile's own slot: thousands of same-address atomics at the
   // end of a launch would serialise at ~12 ns each (MI355X_MICROARCH.md, "fanin")
   uint32_t v[7] = {cnt.steps, cnt.episodes, cnt.illegal, cnt.resets, cnt.sum_len, cnt.reshuffles, cnt.waits};
@@ -1934,6 +2011,7 @@ __global__ __launch_bounds__(SK_SCAN_BLOCK) void k_scan(SkParams P, int list_sel
       eps[pos] = consumed + (uint32_t)r;
       P.busy[g] = (uint8_t)(1 + slot);
       P.cancel[g] = 0;
+      P.plan_tag[g] = P.deal_tag;
     }
     __syncthreads();  // (the shared words are reused by the next stretch)
   }
@@ -1959,6 +2037,13 @@ __global__ __launch_bounds__(256) void k_publish(SkParams P, int list_sel) {
   }
 }
 
+// The pipelined form's hand-over as a kernel of its own, for the host's synchronisation points (get_state, snapshot,
+// seed ...): every dealing launch has finished (the caller's stream waited for the dealing stream), lane = game.
+__global__ __launch_bounds__(256) void k_publish_all(SkParams P) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < P.tiles * SK_TILE) sk_publish_deals(P, g);
+}
+
 template <int NP>
 __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int publish_inline) {
   extern __shared__ uint32_t lds_raw[];
@@ -1969,8 +2054,15 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
   const int i = blockIdx.x * SK_TILE + lane;
   // publish_inline == 2: in line AND its own scan - lane = game, every lane looks at its game's bank itself (what k_scan
   // does, minus the work list: no launch in front of this one; the lanes whose bank is full idle through the refill loops)
-  const bool fused = publish_inline == 2;
-  if (publish_inline && blockIdx.x == 0 && lane == 0) {
+  // publish_inline == 3: beside the step kernel, lane = game as well - the step kernel planned this run on its way out
+  // (sk_plan_deals) and publishes it on its way into a later launch; this kernel deals and signals, as with a work list
+  const bool fused = publish_inline == 2, piped = publish_inline == 3;
+  if (piped && blockIdx.x == 0 && lane == 0) {
+    uint32_t *be = P.bank_empty + (P.deal_tag & 1u);  // the launch that planned this run has finished: its count is complete
+    P.health_host[0] = *be, P.health_host[1] = P.deal_tag;
+    *be = 0;
+  }
+  if (!piped && publish_inline && blockIdx.x == 0 && lane == 0) {
     P.deal_count[list_sel ^ 1] = 0;  // for the next run's k_scan
     // (host-mapped memory: the host adapts the dealing interval.)  Fused, this run's count of empty banks is still being
     // added up by the other wavefronts: the previous run's goes out, each run counts into the word of its list_sel.
@@ -1978,7 +2070,7 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
     P.health_host[0] = *be, P.health_host[1] = P.deal_tag;
     *be = 0;
   }
-  if (!fused && blockIdx.x * SK_TILE >= count) return;
+  if (!fused && !piped && blockIdx.x * SK_TILE >= count) return;
   for (uint32_t k = 0; k < P.debug_deal_delay; k++) __builtin_amdgcn_s_sleep(127);  // (fault injection only: 0 in production)
   const int tile = blockIdx.x;  // stamp slot
   (void)tile;
@@ -2011,6 +2103,13 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
     ep = consumed + (uint32_t)r;
     const unsigned long long be = __ballot(act && r == 0);
     if (be && lane == 0) atomicAdd(P.bank_empty + (list_sel & 1), (uint32_t)__popcll(be));  // (rare)
+  } else if (piped) {
+    const bool listed = i < P.B;
+    g = listed ? i : 0;
+    const int owner = listed ? P.busy[g] : 0;
+    act = owner > 0 && P.plan_tag[g] == P.deal_tag;  // (busy with an older id: a deal of an earlier run that is not published yet)
+    slot = act ? owner - 1 : 0;
+    ep = P.plan_ep[g];
   } else {
     const bool listed = i < count;
     g = listed ? P.deal_list[(size_t)list_sel * G + i] : 0;
@@ -2075,7 +2174,7 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
     if (NP == 0) tile_store(P, P.spare + (size_t)slot * P.tiles * P.L.chunks * SK_TILE, g / SK_TILE, g % SK_TILE, lp);
     STAMP(4);
   }
-  if (publish_inline) {
+  if (publish_inline == 1 || publish_inline == 2) {
     // in line on the caller's stream: no step kernel runs beside this one, so nothing can have cancelled the deal
     // and the next kernel on the stream sees every store - mark the slot ready right here (what k_publish does)
     if (act) {

@@ -248,6 +248,14 @@ def test_inline_dealing_with_work_list_form(N, rng_mode, interval, monkeypatch):
     test_deal_cadence_does_not_change_results(N, rng_mode, interval, False)
 
 
+@pytest.mark.parametrize("N,rng_mode,interval", [(3, 0, 8), (2, 0, 64), (12, 0, 8), (8, 1, 64)])
+def test_dealing_beside_the_step_kernel_with_scan_and_publish_kernels(N, rng_mode, interval, monkeypatch):
+    """Beside the step kernel the dealing runs are pipelined by default (the step kernel plans and publishes them itself);
+    SKYJO_PIPELINED=0 selects the k_scan / k_publish form whose caller's stream waits for every run: same results."""
+    monkeypatch.setenv("SKYJO_PIPELINED", "0")
+    test_deal_cadence_does_not_change_results(N, rng_mode, interval, True)
+
+
 def test_headline_size_properties():
     """BASELINE config 3 (65 536 three-player games): size-independent invariants + an oracle-checked subset."""
     import torch
@@ -310,7 +318,7 @@ def test_dealing_interval_adapts_to_short_episodes():
     cfg = dict(num_players=1, score_penalty=2.0, observe_other_player_indirect=True, mean_reward=1.0,
                reward_refunded=0.001, rng_mode=0, auto_reset=True)
     eng = _engine(B, **cfg)
-    assert eng.overlap() and eng.deal_interval() == 48  # a small batch deals beside the step kernel, one step shorter interval
+    assert eng.overlap() and eng.deal_interval() == 56  # a small batch deals beside the step kernel (pipelined form), shorter interval
     eng.set_overlap(False)
     ora = _oracle_vec(num_envs=B, **cfg)
     eng.seed(None, 5)
