@@ -739,7 +739,7 @@ int skyjo_vec_mlp_forward(const skyjo_vec_mlp *m, const void *records, int32_t r
   if (n == 0) return SKYJO_OK;
   DevGuard guard_(m->device_id);
   SkMlpDraw nodraw{};
-  hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT - 1) / (32 * SKP_GT))), dim3(64), 0, (hipStream_t)stream, m->net,
+  hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT * SKP_WG - 1) / (32 * SKP_GT * SKP_WG))), dim3(64 * SKP_WG), 0, (hipStream_t)stream, m->net,
                      (const uint8_t *)records, (int)record_bytes, m->obs_dim, (long long)n, out, nodraw, m->net, (float *)nullptr);
   HIPCHK(hipGetLastError());
   return SKYJO_OK;
@@ -754,7 +754,7 @@ int skyjo_vec_mlp_act(skyjo_vec *h, const skyjo_vec_mlp *m, const void *records,
   SkMlpDraw d{};
   d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = ticket;
   d.game_id0 = h->P.game_id0, d.actions = actions_out, d.logp = logp_out;
-  hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT - 1) / (32 * SKP_GT))), dim3(64), 0, (hipStream_t)stream, m->net,
+  hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT * SKP_WG - 1) / (32 * SKP_GT * SKP_WG))), dim3(64 * SKP_WG), 0, (hipStream_t)stream, m->net,
                      (const uint8_t *)records, (int)h->P.L.rec_bytes, m->obs_dim, (long long)n, logits_out, d, m->net, (float *)nullptr);
   HIPCHK(hipGetLastError());
   return SKYJO_OK;
@@ -773,7 +773,7 @@ int skyjo_vec_mlp_act_value(skyjo_vec *h, const skyjo_vec_mlp *policy, const sky
   SkMlpDraw d{};
   d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = ticket;
   d.game_id0 = h->P.game_id0, d.actions = actions_out, d.logp = logp_out;
-  hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT - 1) / (32 * SKP_GT)), 2), dim3(64), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT * SKP_WG - 1) / (32 * SKP_GT * SKP_WG)), 2), dim3(64 * SKP_WG), 0, (hipStream_t)stream,
                      policy->net, (const uint8_t *)records, (int)h->P.L.rec_bytes, policy->obs_dim, (long long)n, logits_out, d,
                      value->net, values_out);
   HIPCHK(hipGetLastError());

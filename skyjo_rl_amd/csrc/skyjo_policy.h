@@ -77,22 +77,36 @@ __device__ __forceinline__ skp_bf16x8 skp_frag(const uint4 *p) {
 // One wavefront = SKP_GT column tiles of 32 games: every weight fragment that is loaded feeds SKP_GT independent MFMAs
 // (half the weight traffic per game at 2, and two accumulators in flight instead of one dependent chain).
 // rec_bytes / obs_dim as in the engine's records (indirect observation: 31 int8 features).
-#define SKP_GT 1  // (2: 47.7 us vs 42.7 us per 65 536 records - the kernel is bound by its 512 tanh per game, not by weight traffic)
+#ifndef SKP_GT
+#define SKP_GT 1  // (2, at one wavefront per SIMD: 31.3 vs 32.9 us per iteration of config 5 before the weights moved to LDS)
+#endif
+#ifndef SKP_WAVES
+#define SKP_WAVES 2
+#endif
 // A launch may carry TWO nets over the same records (grid.y = 2): workgroups with blockIdx.y == 1 evaluate `net_b` into
 // `out_b` (no draw) - the policy and the value branch of the action-mask model in one launch (skyjo_vec_mlp_act_value).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_mlp_forward(SkMlpDev net_a, const uint8_t *rec, int rec_bytes, int obs_dim, long long n,
+// A workgroup is SKP_WG wavefronts (eight: two per SIMD, one workgroup per CU) that share ONE copy of the 256 x 256 layer's
+// fragments in LDS (128 KB): read from L2 by every wavefront they were 170 KB per 32 games, 350 MB per 65 536-game launch.
+#ifndef SKP_WG
+#define SKP_WG 8
+#endif
+__global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(SKP_WAVES, SKP_WAVES))) void k_mlp_forward(SkMlpDev net_a, const uint8_t *rec, int rec_bytes, int obs_dim, long long n,
                                                      float *out_a, SkMlpDraw draw_a, SkMlpDev net_b, float *out_b) {
+  __shared__ uint4 w2s[8 * 16 * 64];
   const bool second = blockIdx.y == 1;
   const SkMlpDev net = second ? net_b : net_a;
   float *out = second ? out_b : out_a;
   SkMlpDraw draw = draw_a;
   draw.enable = second ? 0 : draw_a.enable;
-  const int lane = threadIdx.x, col = lane & 31, h = lane >> 5;
+  for (int i = threadIdx.x; i < 8 * 16 * 64; i += 64 * SKP_WG) w2s[i] = net.w2[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+  const long long tile0 = ((long long)blockIdx.x * SKP_WG + (threadIdx.x >> 6)) * SKP_GT;
   long long g[SKP_GT];
   skp_bf16x8 x[SKP_GT][2];
 #pragma unroll
   for (int c = 0; c < SKP_GT; c++) {
-    g[c] = ((long long)blockIdx.x * SKP_GT + c) * 32 + col;
+    g[c] = (tile0 + c) * 32 + col;
     // ---- input fragments: features 16s + 8h .. 16s + 8h + 7 of this lane's game, int8 -> bf16 (exact) ----
     uint32_t ob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (g[c] < n) {
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int ks = 0; ks < 16; ks++) {
       skp_bf16x8 w[SKP_UG];
 #pragma unroll
-      for (int q4 = 0; q4 < SKP_UG; q4++) w[q4] = skp_frag(net.w2 + ((SKP_UG * ug + q4) * 16 + ks) * 64 + lane);
+      for (int q4 = 0; q4 < SKP_UG; q4++) w[q4] = skp_frag(w2s + ((SKP_UG * ug + q4) * 16 + ks) * 64 + lane);
 #pragma unroll
       for (int q4 = 0; q4 < SKP_UG; q4++)
 #pragma unroll
