@@ -354,6 +354,12 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   }
   int rc = SKYJO_OK;
   const size_t N = (size_t)cfg->num_players;
+  // (the largest array first: 164 MB at the headline size, walked in 64-byte pieces by the dealing kernel - it gets the
+  // most contiguous backing a freshly started process can have)
+  if (cfg->rng_mode == SKYJO_RNG_MT19937 && (rc = dalloc(h, &P.mt, h->G * 624 + 16, false)  /* + 16: MtChunkStream::issue reads one word beyond a state */)) {
+    skyjo_vec_destroy(h);
+    return rc;
+  }
   if ((rc = dalloc(h, &P.state, rec16)) || (rc = dalloc(h, &P.spare, SK_BANK * rec16)) ||
       (rc = dalloc(h, &P.spare_ready, SK_BANK * h->G)) || (rc = dalloc(h, &P.bank_head, h->G)) ||
       (rc = dalloc(h, &P.busy, h->G)) || (rc = dalloc(h, &P.cancel, h->G)) || (rc = dalloc(h, &P.done_flag, h->G)) || (rc = dalloc(h, &P.plan_tag, h->G)) || (rc = dalloc(h, &P.plan_ep, h->G)) ||
@@ -364,10 +370,6 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
       (rc = dalloc(h, &P.scores, h->G * N)) || (rc = dalloc(h, &P.done, h->G)) ||
       (rc = dalloc(h, &P.acc_tile, (size_t)P.tiles * SK_ACC_KINDS * SKYJO_MAX_PLAYERS)) || (rc = dalloc(h, &P.dev_error, 1)) ||
       (rc = dalloc(h, &P.counters, 1)) || (rc = dalloc(h, &P.tile_counters, (size_t)P.tiles * 8)) || (rc = dalloc(h, &P.stamps, (size_t)P.tiles * 16))) {
-    skyjo_vec_destroy(h);
-    return rc;
-  }
-  if (cfg->rng_mode == SKYJO_RNG_MT19937 && (rc = dalloc(h, &P.mt, h->G * 624 + 16, false)  /* + 16: MtChunkStream::issue reads one word beyond a state */)) {
     skyjo_vec_destroy(h);
     return rc;
   }

@@ -933,7 +933,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
 // ------------------------------------------------------------------------------------------
 template <bool INDIRECT>
 __device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, const HdrRegs &h, const ObsRegs &ob, int action,
-                                            uint8_t *out, uint4 *held = nullptr) {
+                                            uint8_t *out, uint4 *held = nullptr, const uint4 *pre_a = nullptr, uint32_t pre_b = 0) {
   const int phase = h.w0 & 0xff;
   const uint32_t q0 = ob.q0, q1 = ob.q1, q2 = ob.q2;
   const uint32_t act24 = ((uint32_t)action & 0xffu) << 24;  // byte D of the record: the action this step applied (-1: none)
@@ -946,8 +946,8 @@ __device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, cons
     m[7] = (((h.w0 >> 16) & F_DONE) ? 1u : 0u) | ((h.w0 >> 24) << 8) | ((h.w2 & 0xffffu) << 16);
   }
   // obs[0..15] are chunk 1 of the record; obs[16] = hist[14], obs[17] = discard top, obs[18] = hand card
-  const uint4 a = LQ(1);
-  const uint32_t s8 = (uint32_t)LB(32) | ((h.w1 >> 24) << 8) | ((h.w2 >> 24) << 16);
+  const uint4 a = pre_a ? *pre_a : LQ(1);  // (pre_*: the caller has requested them together with the row)
+  const uint32_t s8 = (pre_a ? pre_b : (uint32_t)LB(32)) | ((h.w1 >> 24) << 8) | ((h.w2 >> 24) << 16);
   if (INDIRECT) {
     uint4 *o = (uint4 *)out;
     uint4 b;
@@ -1218,15 +1218,21 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
       }
       // One read of the expected player's row serves this record and the next iteration's turn.  A draw leaves both the
       // player and his row as they were (the phase is 1 after an applied draw, 0 after a place, a reset or the final draw).
-      if (!((h.w0 & 0xffu) == 1u && (h.w0 >> 24) == SKYJO_ST_OK && a >= 24)) obs_load(P, lp, (h.w0 >> 8) & 0xff, ob);
+      // The expected player's row serves this record and the next iteration's turn; the record's own two reads (the
+      // histogram chunk and bin 14) go out with it: ONE LDS round trip for the whole record.  (The row is re-read even after
+      // a draw, which leaves it as it was: skipped in a branch, its wait sits inside the branch and the record's reads behind
+      // it - k_step 121 -> 117 us.)
+      const uint4 rec_a = LQ(1);
+      const uint32_t rec_b = LB(32);
+      obs_load(P, lp, (h.w0 >> 8) & 0xff, ob);
       if (rec_out) {
         if (INDIRECT) {  // staged in LDS, written by the whole wavefront below
           uint4 rr[4];
-          emit_record<INDIRECT>(P, lp, h, ob, a, nullptr, rr);
+          emit_record<INDIRECT>(P, lp, h, ob, a, nullptr, rr, &rec_a, rec_b);
 #pragma unroll
           for (int p = 0; p < 4; p++) *(uint4 *)(stg + lane * 64 + ((p + (lane >> 1)) & 3) * 16) = rr[p];
         } else {  // direct observation: rec_bytes = 80 / 96 / 112 ...; staged record-major with a stride that spreads the banks
-          emit_record<INDIRECT>(P, lp, h, ob, a, stg + lane * sk_stage_stride(P.L.rec_bytes));
+          emit_record<INDIRECT>(P, lp, h, ob, a, stg + lane * sk_stage_stride(P.L.rec_bytes), nullptr, &rec_a, rec_b);
         }
       }
       if (act_out) __builtin_nontemporal_store(a, &act_out[(size_t)it * P.B + g]);
