@@ -100,6 +100,14 @@ struct skyjo_vec {
   uint8_t *d_records = nullptr;
   uint8_t *d_mask = nullptr;
   std::vector<std::pair<void *, size_t>> allocs;  // every device array of the handle with its size (snapshots copy them all)
+  // The arrays made at create time are carved out of ONE allocation, the large ones at 2 MB boundaries: how the generator
+  // states, the banks and the live tiles lie relative to each other in the memory channels is then the same in every
+  // process.  (With one hipMalloc per array it was not: about one process in twenty - one in three when processes of
+  // different shapes alternate - ran the dealing kernel at 90 instead of 70 us for its whole life.)
+  std::vector<void *> owned;  // what hipFree gets
+  uint8_t *arena = nullptr;
+  size_t arena_off = 0;
+  int arena_mode = 0;  // 1: adding up, 2: carving
   // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[SKYJO_PROF_KERNELS];  // k_step, k_scan, k_deal, k_publish
@@ -121,10 +129,23 @@ namespace {
 
 template <class T>
 int dalloc(skyjo_vec *h, T **out, size_t count, bool zero = true) {
+  const size_t bytes = count * sizeof(T);
   void *p = nullptr;
-  HIPCHK(hipMalloc(&p, count * sizeof(T)));
-  if (zero) HIPCHK(hipMemset(p, 0, count * sizeof(T)));
-  h->allocs.emplace_back(p, count * sizeof(T));
+  if (h->arena_mode) {
+    const size_t al = bytes >= ((size_t)1 << 20) ? ((size_t)2 << 20) : 256;
+    const size_t off = (h->arena_off + al - 1) & ~(al - 1);
+    h->arena_off = off + bytes;
+    if (h->arena_mode == 1) {
+      *out = nullptr;
+      return SKYJO_OK;
+    }
+    p = h->arena + off;
+  } else {
+    HIPCHK(hipMalloc(&p, bytes));
+    h->owned.push_back(p);
+  }
+  if (zero) HIPCHK(hipMemset(p, 0, bytes));
+  h->allocs.emplace_back(p, bytes);
   *out = (T *)p;
   return SKYJO_OK;
 }
@@ -354,22 +375,43 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   }
   int rc = SKYJO_OK;
   const size_t N = (size_t)cfg->num_players;
-  // (the largest array first: 164 MB at the headline size, walked in 64-byte pieces by the dealing kernel - it gets the
-  // most contiguous backing a freshly started process can have)
-  if (cfg->rng_mode == SKYJO_RNG_MT19937 && (rc = dalloc(h, &P.mt, h->G * 624 + 16, false)  /* + 16: MtChunkStream::issue reads one word beyond a state */)) {
-    skyjo_vec_destroy(h);
-    return rc;
+  auto carve = [&]() -> int {
+    int rc = SKYJO_OK;
+    // (the largest array first: 164 MB at the headline size, walked in 64-byte pieces by the dealing kernel - it gets the
+    // most contiguous backing a freshly started process can have)
+    if (cfg->rng_mode == SKYJO_RNG_MT19937 && (rc = dalloc(h, &P.mt, h->G * 624 + 16, false)  /* + 16: MtChunkStream::issue reads one word beyond a state */)) {
+      return rc;
+    }
+    if ((rc = dalloc(h, &P.state, rec16)) || (rc = dalloc(h, &P.spare, SK_BANK * rec16)) ||
+        (rc = dalloc(h, &P.spare_ready, SK_BANK * h->G)) || (rc = dalloc(h, &P.bank_head, h->G)) ||
+        (rc = dalloc(h, &P.busy, h->G)) || (rc = dalloc(h, &P.cancel, h->G)) || (rc = dalloc(h, &P.done_flag, h->G)) || (rc = dalloc(h, &P.plan_tag, h->G)) || (rc = dalloc(h, &P.plan_ep, h->G)) ||
+        (rc = dalloc(h, &P.deal_list, 2 * h->G)) || (rc = dalloc(h, &P.deal_ep, 2 * h->G)) ||
+        (rc = dalloc(h, &P.deal_count, 2)) || (rc = dalloc(h, &P.bank_empty, 2)) ||
+        (rc = dalloc(h, &P.mt_idx, (1 + SK_BANK) * h->G)) || (rc = dalloc(h, &P.seeds, h->G)) ||
+        (rc = dalloc(h, &P.deals_consumed, h->G)) || (rc = dalloc(h, &P.rewards, h->G * N)) ||
+        (rc = dalloc(h, &P.scores, h->G * N)) || (rc = dalloc(h, &P.done, h->G)) ||
+        (rc = dalloc(h, &P.acc_tile, (size_t)P.tiles * SK_ACC_KINDS * SKYJO_MAX_PLAYERS)) || (rc = dalloc(h, &P.dev_error, 1)) ||
+        (rc = dalloc(h, &P.counters, 1)) || (rc = dalloc(h, &P.tile_counters, (size_t)P.tiles * 8)) || (rc = dalloc(h, &P.stamps, (size_t)P.tiles * 16))) {
+      return rc;
+    }
+    return SKYJO_OK;
+  };
+  h->arena_mode = 1, h->arena_off = 0;
+  (void)carve();
+  {
+    const size_t two_mb = (size_t)2 << 20, total = h->arena_off + two_mb;
+    void *raw = nullptr;
+    if (hipMalloc(&raw, total) != hipSuccess) {
+      skyjo_vec_destroy(h);
+      return fail(SKYJO_E_DEVICE, "hipMalloc failed for the engine's arrays");
+    }
+    h->owned.push_back(raw);
+    h->arena = (uint8_t *)(((uintptr_t)raw + two_mb - 1) & ~(uintptr_t)(two_mb - 1));
   }
-  if ((rc = dalloc(h, &P.state, rec16)) || (rc = dalloc(h, &P.spare, SK_BANK * rec16)) ||
-      (rc = dalloc(h, &P.spare_ready, SK_BANK * h->G)) || (rc = dalloc(h, &P.bank_head, h->G)) ||
-      (rc = dalloc(h, &P.busy, h->G)) || (rc = dalloc(h, &P.cancel, h->G)) || (rc = dalloc(h, &P.done_flag, h->G)) || (rc = dalloc(h, &P.plan_tag, h->G)) || (rc = dalloc(h, &P.plan_ep, h->G)) ||
-      (rc = dalloc(h, &P.deal_list, 2 * h->G)) || (rc = dalloc(h, &P.deal_ep, 2 * h->G)) ||
-      (rc = dalloc(h, &P.deal_count, 2)) || (rc = dalloc(h, &P.bank_empty, 2)) ||
-      (rc = dalloc(h, &P.mt_idx, (1 + SK_BANK) * h->G)) || (rc = dalloc(h, &P.seeds, h->G)) ||
-      (rc = dalloc(h, &P.deals_consumed, h->G)) || (rc = dalloc(h, &P.rewards, h->G * N)) ||
-      (rc = dalloc(h, &P.scores, h->G * N)) || (rc = dalloc(h, &P.done, h->G)) ||
-      (rc = dalloc(h, &P.acc_tile, (size_t)P.tiles * SK_ACC_KINDS * SKYJO_MAX_PLAYERS)) || (rc = dalloc(h, &P.dev_error, 1)) ||
-      (rc = dalloc(h, &P.counters, 1)) || (rc = dalloc(h, &P.tile_counters, (size_t)P.tiles * 8)) || (rc = dalloc(h, &P.stamps, (size_t)P.tiles * 16))) {
+  h->arena_mode = 2, h->arena_off = 0;
+  rc = carve();
+  h->arena_mode = 0;
+  if (rc) {
     skyjo_vec_destroy(h);
     return rc;
   }
@@ -415,7 +457,7 @@ int skyjo_vec_destroy(skyjo_vec *h) {
   if (h->deal_stream) (void)hipStreamDestroy(h->deal_stream);
   if (h->ev_scan) (void)hipEventDestroy(h->ev_scan);
   if (h->ev_dealt) (void)hipEventDestroy(h->ev_dealt);
-  for (auto &p : h->allocs) (void)hipFree(p.first);
+  for (void *p : h->owned) (void)hipFree(p);
   for (auto &v : h->ev)
     for (auto &e : v) (void)hipEventDestroy(e.first), (void)hipEventDestroy(e.second);
   if (h->health_host) (void)hipHostFree(h->health_host);
