@@ -694,8 +694,7 @@ __device__ __forceinline__ uint32_t pack12(uint32_t a, uint32_t b, uint32_t c) {
 struct ObsRegs {
   uint32_t q0, q1, q2, nz0, nz1, nz2, hd0, hd1, hd2;
 };
-__device__ __forceinline__ void obs_load(const SkParams &P, uint8_t *lp, int q, ObsRegs &o) {
-  const uint4 row = LQ((sk_pb(P.L, q) + PB_VIS) >> 4);  // (the fourth word is the placed counter)
+__device__ __forceinline__ void obs_from_row(const uint4 &row, ObsRegs &o) {  // (the fourth word is the placed counter)
   o.q0 = row.x, o.q1 = row.y, o.q2 = row.z;
   o.nz0 = swar_nonzero01(o.q0 ^ 0xf2f2f2f2u);  // vis != -14  <=> players_masked != 0
   o.nz1 = swar_nonzero01(o.q1 ^ 0xf2f2f2f2u);
@@ -703,6 +702,10 @@ __device__ __forceinline__ void obs_load(const SkParams &P, uint8_t *lp, int q, 
   o.hd0 = swar_nonzero01(o.q0 ^ 0x0f0f0f0fu) ^ 0x01010101u;  // vis == 15 <=> players_masked == 2
   o.hd1 = swar_nonzero01(o.q1 ^ 0x0f0f0f0fu) ^ 0x01010101u;
   o.hd2 = swar_nonzero01(o.q2 ^ 0x0f0f0f0fu) ^ 0x01010101u;
+}
+__device__ __forceinline__ void obs_load(const SkParams &P, uint8_t *lp, int q, ObsRegs &o) {
+  const uint4 row = LQ((sk_pb(P.L, q) + PB_VIS) >> 4);
+  obs_from_row(row, o);
 }
 
 // uniform choice over the legal actions == policy_ra's p = mask / sum(mask)
@@ -1224,7 +1227,9 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
       // it - k_step 121 -> 117 us.)
       const uint4 rec_a = LQ(1);
       const uint32_t rec_b = LB(32);
-      obs_load(P, lp, (h.w0 >> 8) & 0xff, ob);
+      const uint4 rec_row = LQ((sk_pb(P.L, (h.w0 >> 8) & 0xff) + PB_VIS) >> 4);
+      asm volatile("" ::: "memory");  // (all three requests stay up here: the compiler would sink the record's two into the record's branch)
+      obs_from_row(rec_row, ob);
       if (rec_out) {
         if (INDIRECT) {  // staged in LDS, written by the whole wavefront below
           uint4 rr[4];
