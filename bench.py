@@ -9,7 +9,8 @@ random admissible policy (state transition + observation / action-mask build, th
 with the applied action written to HBM) and finished games take their next deal - plus the dealing
 run (k_scan + k_deal) that the engine starts once per 88 iterations.  So `--steps 20 --warmup 5` are
 1 760 timed lockstep iterations after 440 untimed ones (about 16 episodes per game inside the timed
-region); the defaults are 250 / 25 launches.  The workload is BASELINE.json configs[2]: 65 536
+region); the defaults are 250 / 25 launches.  Before the warm-up the freshly seeded games are run for 100 launches
+(set-up: seeded together they end their first episodes together).  The workload is BASELINE.json configs[2]: 65 536
 parallel 3-player games per GPU, DEFAULT_CONFIG (indirect observation, D = 31), game g seeded
 base + g, numpy-legacy MT19937 deals (bit-identical to the reference).  `value` = env-steps (applied
 actions, counted on device) of all ranks / max-over-ranks wall time, inputs resident in HBM.  One
@@ -39,6 +40,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
 CHUNK = int(os.environ.get("SKYJO_BENCH_CHUNK", "0"))  # lockstep iterations per kernel launch; 0 = the engine's dealing interval
+SETTLE = int(os.environ.get("SKYJO_BENCH_SETTLE", "100"))  # launches between seeding and the warm-up (see main)
                                                         # (88 for three and more players, <= kMaxRolloutChunk in skyjo_capi.hip)
 
 
@@ -166,6 +168,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Set-up, not part of W or K: freshly seeded, all games start their first episode in the same iteration and end it within
+    # a few iterations of each other - bursts of resets and deals instead of the steady 0.95 % per iteration.  It takes some
+    # 50 episodes per game until the ends are spread evenly (measured: 20 timed launches after 5 / 25 / 50 / 100 / 200 launches:
+    # 2.91 / 2.92 / 3.01 / 3.05 / 3.04 x 10^10 steps/s), so the games are run for SETTLE launches before the warm-up starts.
+    run(SETTLE)
     run(args.warmup)
     barrier()
     c0 = eng.counters()
@@ -235,6 +242,7 @@ def main():
                                    if record else f"{B} x {N}-player games per GPU, no records",
                        "games_per_gpu": B, "num_players": N, "rng_mode": args.rng,
                        "iterations_per_step": CHUNK, "timed_iterations": args.steps * CHUNK, "warmup_iterations": args.warmup * CHUNK,
+                       "settle_launches_before_warmup": SETTLE,
                        "dealing": ("beside k_step (own stream; k_scan + k_publish)" if os.environ.get("SKYJO_PIPELINED") == "0" else
                                    "beside k_step (own stream; planned and published by k_step itself)") if eng.overlap() else
                                   ("in line (k_scan + k_deal)" if os.environ.get("SKYJO_FUSED_SCAN") == "0" else "in line (k_deal scans the banks itself)"),
