@@ -256,6 +256,72 @@ def test_dealing_beside_the_step_kernel_with_scan_and_publish_kernels(N, rng_mod
     test_deal_cadence_does_not_change_results(N, rng_mode, interval, True)
 
 
+@pytest.mark.parametrize("seed,N,B", [(1, 3, 1024), (2, 2, 700), (3, 4, 2048)])
+def test_mixed_calls_while_dealing_runs_are_in_flight(seed, N, B):
+    """Every kind of call in a random order while dealing runs are pipelined beside the step kernel (small batch: on by
+    default): fused rollouts of any length, single steps with caller actions, masked resets, re-seeding one game,
+    snapshot / run on / restore, switching the dealing between the two streams and changing its interval.  After every
+    call the engine shows what the oracle shows."""
+    import torch
+
+    cfg = dict(num_players=N, score_penalty=2.0, observe_other_player_indirect=True, mean_reward=1.0,
+               reward_refunded=0.001, rng_mode=0, auto_reset=True)
+    eng = _engine(B, **cfg)
+    ora = _oracle_vec(num_envs=B, **cfg)
+    assert eng.overlap()
+    eng.seed(None, 77)
+    ora.seed(None, 77)
+    rng = np.random.default_rng(seed)
+    pol = 0
+
+    def same(tag):
+        obs, mask, agent, phase = ora.observe()
+        o = eng.observe_host()
+        np.testing.assert_array_equal(o.observations, obs, err_msg=tag)
+        np.testing.assert_array_equal(o.action_mask, mask, err_msg=tag)
+        np.testing.assert_array_equal(o.agent, agent, err_msg=tag)
+        np.testing.assert_array_equal(o.phase, phase, err_msg=tag)
+
+    for r in range(70):
+        op = rng.choice(["rollout", "rollout", "rollout", "step", "reset", "seed_one", "snapshot", "overlap", "interval"])
+        if op == "rollout":
+            k = int(rng.integers(1, 120))
+            pol += 1
+            act = torch.empty((k, B), dtype=torch.int32, device="cuda")
+            eng.rollout(k, policy_seed=pol, actions=act)
+            np.testing.assert_array_equal(act.cpu().numpy(), ora.rollout(k, pol, record_actions=True), err_msg=f"round {r}")
+        elif op == "step":
+            for _ in range(int(rng.integers(1, 6))):
+                obs, mask, agent, phase = ora.observe()
+                acts = np.argmax(rng.random((B, 26)) * mask, axis=1).astype(np.int32)
+                ora.step(acts)
+                o = eng.step_host(acts)
+                np.testing.assert_array_equal(o.status, ora.status, err_msg=f"round {r}")
+                np.testing.assert_array_equal(o.done, ora.dones, err_msg=f"round {r}")
+        elif op == "reset":
+            m = (rng.random(B) < 0.05).astype(np.uint8)
+            ora.reset(m)
+            eng.reset_host(m)
+        elif op == "seed_one":
+            g, v = int(rng.integers(0, B)), int(rng.integers(0, 1 << 30))
+            ora.seed_one(g, v)
+            eng.seed_one(g, v)
+        elif op == "snapshot":
+            snap = eng.snapshot()
+            eng.rollout(int(rng.integers(1, 60)), policy_seed=999)
+            eng.restore(snap)
+        elif op == "overlap":
+            eng.set_overlap(bool(rng.integers(0, 2)))
+        else:
+            eng.set_deal_interval(int(rng.integers(4, 100)))
+        same(f"round {r} after {op}")
+    c, oc = eng.counters(), ora.counters()
+    for k in ("steps", "episodes", "resets", "sum_len"):
+        assert c[k] == oc[k], (k, c[k], oc[k])
+    assert c["episodes"] > 0
+    eng.close()
+
+
 def test_headline_size_properties():
     """BASELINE config 3 (65 536 three-player games): size-independent invariants + an oracle-checked subset."""
     import torch
