@@ -1,4 +1,4 @@
-"""Learner side of the rollout hand-off: a minimal clipped-PPO update that consumes the columns of
+"""EXAMPLE, not part of the package (SURVEY C5 - RLlib training - is out of scope).  Learner side of the rollout hand-off: a minimal clipped-PPO update that consumes the columns of
 ``rollout.RolloutBuffer`` - what ``rlskyjo/models/train_model_simple_rllib.py:22-59`` has RLlib's PPO trainer do with the
 sample batches of its rollout workers.  The trainer itself (Ray, tune, checkpoints) stays out of scope; this file shows
 that the buffer is sufficient for a learner and closes the loop  collect (HIP kernels) -> update (torch autograd on
@@ -10,7 +10,7 @@ an episode).  Steps of episodes that did not finish inside the buffer carry no r
 """
 import torch
 
-from .action_mask_model import FLOAT_MIN, FusedNet
+from skyjo_rl_amd.action_mask_model import FLOAT_MIN, FusedNet
 
 
 @torch.no_grad()

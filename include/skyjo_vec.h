@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SKYJO_ABI_VERSION 2
+#define SKYJO_ABI_VERSION 3
 #define SKYJO_MAX_PLAYERS 12 /* skyjo.py:24-26 */
 #define SKYJO_NUM_ACTIONS 26 /* skyjo.py:46 */
 #define SKYJO_NUM_CARDS 150  /* skyjo.py:80 */
@@ -52,6 +52,7 @@ extern "C" {
 #define SKYJO_ST_ILLEGAL 1   /* action masked out or out of range: TerminateIllegalWrapper semantics */
 #define SKYJO_ST_NOOP_DONE 2 /* game already over and auto_reset off (skyjo.py:316-321) */
 #define SKYJO_ST_RESET 3     /* game was over: a new episode was dealt, the action was ignored */
+#define SKYJO_ST_ERROR 4     /* the engine raised a device error (skyjo_vec_check_error): the game is frozen until re-seeded */
 
 /* skyjo_vec_step: a game whose action is SKYJO_ACTION_SKIP is left exactly as it is (no step, no reset; its record is
  * still written) - the single-game views use it to step ONE game of a shared engine (SkyjoGame(engine=, index=)). */
@@ -82,8 +83,9 @@ typedef struct skyjo_vec_config {
 /* Output record: one per game per step, `record_bytes` long (64 for the indirect observation):
  *   [0, D)            int8 observations            (skyjo.py:180-190)
  *   [D]               int8 the action the step that wrote this record applied to the game (-1: none - the game was
- *                     reset / already over / skipped, or the record comes from reset / observe); D is odd, so the
- *                     byte is the padding between the observation and the mask
+ *                     reset / already over / skipped, or the record comes from reset / observe; -2: the caller's action
+ *                     was outside 0 .. 25 and refused as illegal); D is odd, so the byte is the padding between the
+ *                     observation and the mask
  *   [Dp, Dp+26)       int8 action_mask, Dp = (D+3)&~3 (skyjo.py:201-224)
  *   [Dp+26]           expected player (agent id)   (skyjo.py:503)
  *   [Dp+27]           phase 0 = draw, 1 = place
@@ -178,6 +180,12 @@ const double *skyjo_vec_rewards_ptr(const skyjo_vec *h);
 const double *skyjo_vec_scores_ptr(const skyjo_vec *h);
 const uint8_t *skyjo_vec_done_ptr(const skyjo_vec *h);
 
+/* Sticky device error of the handle: 0, or SKYJO_E_DEVICE with the reason in skyjo_vec_last_error() - today the one case
+ * is a step kernel that gave up waiting for the dealing kernel that should run beside it (SKYJO_OPT_OVERLAP); the games
+ * concerned are frozen (SKYJO_ST_ERROR), results since then are void, skyjo_vec_seed clears it.  Synchronises `stream`.
+ * Every synchronising call below (and the *_host conveniences, snapshot_create) makes the same check by itself. */
+int skyjo_vec_check_error(skyjo_vec *h, void *stream);
+
 /* synchronising host-side accessors */
 int skyjo_vec_get_counters(skyjo_vec *h, skyjo_vec_counters *out_host, void *stream);
 int skyjo_vec_reset_counters(skyjo_vec *h, void *stream);
@@ -248,11 +256,17 @@ int skyjo_vec_sample_actions(skyjo_vec *h, const void *records, const float *log
  * TorchActionMaskModel builds it (rlskyjo/models/action_mask_model.py:41-52: obs -> 256 tanh -> 256 tanh -> outputs),
  * evaluated for n records in one kernel that reads the int8 observation out of each record (indirect observation,
  * obs_dim <= 31).  Weights are given once in torch.nn.Linear layout (row-major [out][in], float32, HOST pointers) and
- * kept on the device as bf16 MFMA fragments; accumulation is float32.  out: float32 [n][out_dim] (device), out_dim <= 32
- * (26 logits for the policy branch, 1 for the value branch).  Agreement with the float32 torch module is that of bf16
- * weights and activations: see tests/test_gpu_policy_net.py for the stated tolerances. */
+ * kept on the device as bf16 MFMA fragments (one per weight, or a high and a low one: see SKYJO_MLP_*); accumulation is
+ * float32.  out: float32 [n][out_dim] (device), out_dim <= 32 (26 logits for the policy branch, 1 for the value branch).
+ * tests/test_gpu_policy_net.py states the tolerance of either precision against the float32 torch module. */
 typedef struct skyjo_vec_mlp skyjo_vec_mlp; /* opaque */
-int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, const float *w1, const float *b1,
+/* precision of a packed net.  SKYJO_MLP_FP32 is the drop-in for the reference's float32 TorchFC
+ * (action_mask_model.py:43-49): every operand is the sum of two bf16 values and every product three MFMAs into a float32
+ * accumulator, logits / values within 1e-4 of the float32 module (tests/test_gpu_policy_net.py).  SKYJO_MLP_BF16 keeps
+ * weights and activations as single bf16 values: a third of the matrix work, logits within 8e-2. */
+#define SKYJO_MLP_BF16 0
+#define SKYJO_MLP_FP32 1
+int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, int32_t precision, const float *w1, const float *b1,
                          const float *w2, const float *b2, const float *w3, const float *b3, skyjo_vec_mlp **out);
 int skyjo_vec_mlp_destroy(skyjo_vec_mlp *m);
 int skyjo_vec_mlp_forward(const skyjo_vec_mlp *m, const void *records, int32_t record_bytes, int64_t n, float *out,
@@ -272,6 +286,34 @@ int skyjo_vec_mlp_act_value(skyjo_vec *h, const skyjo_vec_mlp *policy, const sky
  * episode ended in that step - episode_end_out uint8 [num_envs] - and copy their final rewards (skyjo_env.py:293-312)
  * into final_rewards_out double [num_envs][num_players], zeros elsewhere.  One small kernel, no host traffic. */
 int skyjo_vec_episode_ends(skyjo_vec *h, const void *records, double *final_rewards_out, uint8_t *episode_end_out, void *stream);
+
+/* skyjo_vec_step that also does what skyjo_vec_episode_ends does, inside the step kernel (no extra launch): the lane that
+ * ends an episode writes episode_end_out[game] = 1 and the game's final rewards, every other game 0 / zeros. */
+int skyjo_vec_step_collect(skyjo_vec *h, const int32_t *actions, void *records_out, double *final_rewards_out,
+                           uint8_t *episode_end_out, void *stream);
+
+/* Config 5's collection loop in ONE call (what rlskyjo/models/train_model_simple_rllib.py:22-59 has RLlib's
+ * rollout workers do, per step: forward of the action-mask model, masked draw, env step, bookkeeping of episode ends): T
+ * lockstep iterations of  [policy (+ value) net with the draw in its epilogue] -> [step kernel with the episode-end
+ * columns] - two launches per iteration, nothing on the host in between.  All buffers are device memory of the caller:
+ *   records        [T+1][num_envs][record_bytes]  IN: records[0] = what the first actor sees (skyjo_vec_observe / the last
+ *                                                  records of the previous call); OUT: records[t+1] = after step t
+ *   actions        int32 [T][num_envs]            the drawn actions
+ *   logp           float32 [T][num_envs] or NULL  their log-probabilities
+ *   values         float32 [T+1][num_envs][value out_dim]  (required iff `value` is given; [T] = bootstrap value)
+ *   final_rewards  double [T][num_envs][num_players] and episode_end uint8 [T][num_envs]: both or neither
+ * The draw of iteration t uses (seed, first_ticket + t) as in skyjo_vec_mlp_act: the same call sequence made one launch at a
+ * time from the host gives the same bits. */
+typedef struct skyjo_vec_rollout_buffers {
+  void *records;
+  int32_t *actions;
+  float *logp;
+  float *values;
+  double *final_rewards;
+  uint8_t *episode_end;
+} skyjo_vec_rollout_buffers;
+int skyjo_vec_model_rollout(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, int32_t T, uint64_t seed,
+                            uint64_t first_ticket, int32_t no_masking, const skyjo_vec_rollout_buffers *buffers, void *stream);
 
 /* host-pointer conveniences for small batches (single-game AEC view): synchronous */
 int skyjo_vec_step_host(skyjo_vec *h, const int32_t *actions_host, void *records_out_host);

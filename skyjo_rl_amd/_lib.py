@@ -9,10 +9,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SKYJO_LIB") or os.path.join(_HERE, "libskyjo_vec.so")  # SKYJO_LIB: diagnostic builds
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_PLAYERS = 12
-ST_OK, ST_ILLEGAL, ST_NOOP_DONE, ST_RESET = 0, 1, 2, 3
+ST_OK, ST_ILLEGAL, ST_NOOP_DONE, ST_RESET, ST_ERROR = 0, 1, 2, 3, 4
 RNG_MT19937, RNG_PHILOX = 0, 1
+MLP_BF16, MLP_FP32 = 0, 1  # SKYJO_MLP_*: precision of a packed policy / value net
 ACTION_SKIP = -1000  # SKYJO_ACTION_SKIP: leave this game as it is (skyjo_vec_step)
 PROF_KERNELS = ("k_step", "k_scan", "k_deal", "k_publish")
 
@@ -52,6 +53,10 @@ class GameState(C.Structure):
                 ("rewards", C.c_double * MAX_PLAYERS)]
 
 
+class RolloutBuffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("records", "actions", "logp", "values", "final_rewards", "episode_end")]
+
+
 # name -> (restype, argtypes); this table is also what tests/test_capi_symbols.py checks against the header
 VP, I32, I64, U64, U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32
 SIGNATURES = {
@@ -68,15 +73,18 @@ SIGNATURES = {
     "skyjo_vec_observe": (C.c_int, [VP, VP, VP, VP]),
     "skyjo_vec_unpack": (C.c_int, [VP, VP, I64, VP, VP, VP, VP, VP, VP, VP]),
     "skyjo_vec_sample_actions": (C.c_int, [VP, VP, VP, I64, U64, U64, I32, VP, VP, VP, VP]),
-    "skyjo_vec_mlp_create": (C.c_int, [I32, I32, I32, VP, VP, VP, VP, VP, VP, C.POINTER(VP)]),
+    "skyjo_vec_mlp_create": (C.c_int, [I32, I32, I32, I32, VP, VP, VP, VP, VP, VP, C.POINTER(VP)]),
     "skyjo_vec_mlp_destroy": (C.c_int, [VP]),
     "skyjo_vec_mlp_forward": (C.c_int, [VP, VP, I32, I64, VP, VP]),
     "skyjo_vec_mlp_act": (C.c_int, [VP, VP, VP, I64, U64, U64, I32, VP, VP, VP, VP]),
     "skyjo_vec_mlp_act_value": (C.c_int, [VP, VP, VP, VP, I64, U64, U64, I32, VP, VP, VP, VP, VP]),
     "skyjo_vec_episode_ends": (C.c_int, [VP, VP, VP, VP, VP]),
+    "skyjo_vec_step_collect": (C.c_int, [VP, VP, VP, VP, VP, VP]),
+    "skyjo_vec_model_rollout": (C.c_int, [VP, VP, VP, I32, U64, U64, I32, C.POINTER(RolloutBuffers), VP]),
     "skyjo_vec_rewards_ptr": (VP, [VP]),
     "skyjo_vec_scores_ptr": (VP, [VP]),
     "skyjo_vec_done_ptr": (VP, [VP]),
+    "skyjo_vec_check_error": (C.c_int, [VP, VP]),
     "skyjo_vec_get_counters": (C.c_int, [VP, C.POINTER(Counters), VP]),
     "skyjo_vec_reset_counters": (C.c_int, [VP, VP]),
     "skyjo_vec_get_state": (C.c_int, [VP, I32, C.POINTER(GameState), VP]),

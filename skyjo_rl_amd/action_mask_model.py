@@ -6,9 +6,9 @@ default fully connected net (two tanh layers of 256 units, separate value branch
 consumes the zero-copy views of the engine's record tensor directly on the GPU (``SkyjoVecEnv.split``),
 so a PPO-style rollout never leaves the device.  ``ActionMaskModel`` / ``sample_actions`` are the plain-torch
 statement of the model (float32) and the test reference.  Behind the C ABI the same model runs as hand-written
-gfx950 kernels: ``FusedNet`` packs one branch for the matrix cores (``skyjo_vec_mlp_*``, csrc/skyjo_policy.h: bf16
-weights and activations, float32 accumulation - a documented deviation from the float32 module, tolerances in
-tests/test_gpu_policy_net.py), ``FusedNet.act`` adds the masking + categorical draw in the net's epilogue, and with
+gfx950 kernels: ``FusedNet`` packs one branch for the matrix cores (``skyjo_vec_mlp_*``, csrc/skyjo_policy.h: float32-grade
+by default - bf16-pair operands, float32 accumulation, within 1e-4 of the float32 module - or plain bf16 operands as the
+fast mode; tolerances in tests/test_gpu_policy_net.py), ``FusedNet.act`` adds the masking + categorical draw in the net's epilogue, and with
 ``value_net=`` the value branch rides in the same launch (``skyjo_vec_mlp_act_value``).
 """
 import torch
@@ -67,10 +67,13 @@ def sample_actions_fused(model, env, records, seed=0, ticket=0, logp=None):
 
 class FusedNet:
     """One branch of the model (``model.policy`` or ``model.value``: Linear-Tanh-Linear-Tanh-Linear with 256 hidden
-    units) packed for the MI355X matrix cores (``skyjo_vec_mlp_*``, csrc/skyjo_policy.h): bf16 weights as MFMA
-    fragments, float32 accumulation, observations read straight from the engine's records."""
+    units) packed for the MI355X matrix cores (``skyjo_vec_mlp_*``, csrc/skyjo_policy.h): weights as bf16 MFMA
+    fragments (pairs of them in the float32-grade mode), float32 accumulation, observations read straight from the
+    engine's records."""
 
-    def __init__(self, seq, device=0):
+    def __init__(self, seq, device=0, precision="fp32"):
+        """``precision``: "fp32" (default; the reference's TorchFC is float32 - every operand a bf16 pair, outputs within 1e-4
+        of ``seq`` itself) or "bf16" (single bf16 operands: a third of the matrix work, outputs within 8e-2)."""
         import ctypes as C
 
         import numpy as np
@@ -85,7 +88,9 @@ class FusedNet:
                      np.ascontiguousarray(lin.bias.detach().float().cpu().numpy())]
         self._L = _lib.load()
         h = C.c_void_p()
+        self.precision = precision
         _lib.check(self._L.skyjo_vec_mlp_create(int(device), self.obs_dim, self.out_dim,
+                                                {"bf16": _lib.MLP_BF16, "fp32": _lib.MLP_FP32}[precision],
                                                 *[a.ctypes.data_as(C.c_void_p) for a in arrs], C.byref(h)))
         self._h, self._C, self._check = h, C, _lib.check
 

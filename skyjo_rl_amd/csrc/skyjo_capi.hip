@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <new>
 #include <string>
@@ -16,6 +17,7 @@
 namespace {
 
 thread_local std::string g_err;
+std::atomic<uint64_t> g_generation{0};
 
 int fail(int code, const std::string &msg) {
   g_err = msg;
@@ -69,6 +71,7 @@ struct skyjo_vec_mlp {
 };
 
 struct skyjo_vec {
+  uint64_t generation = 0;  // unique per created handle in this process (snapshots remember it)
   skyjo_vec_config cfg{};
   SkParams P{};
   size_t G = 0;           // tiles * 64
@@ -115,6 +118,8 @@ struct skyjo_vec {
 
 struct skyjo_vec_snapshot {
   const skyjo_vec *owner = nullptr;
+  uint64_t owner_generation = 0;     // the handle's id (an address can be reused by a later handle)
+  std::vector<size_t> array_bytes;   // size of every array in the blob, in the order of the handle's table
   int device_id = 0;
   void *blob = nullptr;
   size_t bytes = 0;
@@ -126,6 +131,15 @@ struct skyjo_vec_snapshot {
 };
 
 namespace {
+
+// The sticky device error (skyjo_device.h: SK_ERR_*), as the kernels left it in the host-mapped word: valid after any
+// synchronisation with the stream the kernels ran on.
+int dev_error_check(const skyjo_vec *h) {
+  if (h->health_host && (h->health_host[2] & SK_ERR_DEAL_TIMEOUT))
+    return fail(SKYJO_E_DEVICE, "a step kernel gave up waiting for the dealing kernel that should run beside it (SKYJO_OPT_OVERLAP): "
+                                "results since then are void; switch the option off or re-seed");
+  return SKYJO_OK;
+}
 
 template <class T>
 int dalloc(skyjo_vec *h, T **out, size_t count, bool zero = true) {
@@ -282,7 +296,7 @@ int start_deals_piped(skyjo_vec *h, hipStream_t s) {
 }
 
 int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions, uint8_t *rec, int32_t *act_out,
-                int iters, uint64_t policy_seed) {
+                int iters, uint64_t policy_seed, double *end_rew = nullptr, uint8_t *end_flag = nullptr) {
   dim3 grid(h->P.tiles), block(SK_TILE);
   const bool ind = h->P.L.indirect != 0;
   int rc;
@@ -291,7 +305,7 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
   if (h->deal_inflight && h->inflight_piped) h->P.ov_flags |= 1u;  // publish what has been dealt since (sk_publish_deals)
 #define LAUNCH3(I, Pol, NP)                                                                                       \
   hipExtLaunchKernelGGL((k_step<I, Pol, NP>), grid, block, (uint32_t)h->lds_bytes, s, e0, e1, 0, h->P, actions,   \
-                        rec, act_out, iters, policy_seed, h->iter)
+                        rec, act_out, iters, policy_seed, h->iter, end_rew, end_flag)
 #define LAUNCH(I, Pol)                                \
   switch (h->P.L.N) {                                 \
     case 2: LAUNCH3(I, Pol, 2); break;                \
@@ -319,6 +333,20 @@ int fetch_record(skyjo_vec *h, const uint4 *base, int game, std::vector<uint8_t>
   const uint8_t *src = (const uint8_t *)(base + ((size_t)(game / SK_TILE) * L.chunks) * SK_TILE + game % SK_TILE);
   HIPCHK(hipMemcpy2DAsync(raw.data(), 16, src, SK_TILE * 16, 16, L.chunks, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  return SKYJO_OK;
+}
+
+// One launch of the policy net (nets == 2: policy and value branch over the same records, grid.y = 2) in the net's precision.
+int launch_mlp(const SkMlpDev &a, const SkMlpDev &b, int nets, const uint8_t *rec, int rec_bytes, int obs_dim, int64_t n, float *out_a,
+               const SkMlpDraw &draw, float *out_b, hipStream_t s) {
+  const dim3 grid((unsigned)((n + 32 * SKP_GT * SKP_WG - 1) / (32 * SKP_GT * SKP_WG)), (unsigned)nets), block(64 * SKP_WG);
+  if (a.split) {
+    static_assert(SKP_GT == 1, "the float32-grade kernel handles one tile of 32 games per wavefront");
+    hipLaunchKernelGGL(k_mlp_forward_split, grid, block, 0, s, a, rec, rec_bytes, obs_dim, (long long)n, out_a, draw, b, out_b);
+  } else {
+    hipLaunchKernelGGL(k_mlp_forward, grid, block, 0, s, a, rec, rec_bytes, obs_dim, (long long)n, out_a, draw, b, out_b);
+  }
+  HIPCHK(hipGetLastError());
   return SKYJO_OK;
 }
 
@@ -351,6 +379,7 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   skyjo_vec *h = new (std::nothrow) skyjo_vec();
   if (!h) return fail(SKYJO_E_INVALID, "out of host memory");
   h->cfg = *cfg;
+  h->generation = ++g_generation;
   SkParams &P = h->P;
   P.L = sk_make_layout(cfg->num_players, cfg->observe_indirect);
   P.B = cfg->num_envs;
@@ -425,12 +454,12 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   }
   {
     void *dp = nullptr;
-    if (hipHostMalloc((void **)&h->health_host, 2 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+    if (hipHostMalloc((void **)&h->health_host, 4 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(&dp, h->health_host, 0) != hipSuccess) {
       skyjo_vec_destroy(h);
       return fail(SKYJO_E_DEVICE, "cannot map the bank-health word");
     }
-    h->health_host[0] = h->health_host[1] = 0;
+    h->health_host[0] = h->health_host[1] = h->health_host[2] = h->health_host[3] = 0;
     P.health_host = (volatile uint32_t *)dp;
   }
   // The dealing kernel runs beside the step kernel (own stream) when the batch leaves SIMDs free: up to 768 tiles of
@@ -482,8 +511,10 @@ int skyjo_vec_seed(skyjo_vec *h, const uint64_t *seeds_host, uint64_t base_seed,
     HIPCHK(hipMalloc((void **)&d_seeds, sizeof(uint64_t) * (size_t)h->P.B));
     HIPCHK(hipMemcpyAsync(d_seeds, seeds_host, sizeof(uint64_t) * (size_t)h->P.B, hipMemcpyHostToDevice, s));
   }
+  HIPCHK(hipDeviceSynchronize());  // (nothing of the old life of the handle is still running)
   HIPCHK(hipMemsetAsync(h->P.done, 0, h->G, s));
   HIPCHK(hipMemsetAsync(h->P.dev_error, 0, sizeof(uint32_t), s));  // a new seeding starts from a clean slate
+  h->health_host[2] = 0;
   int rc0;
   if ((rc0 = publish_deals(h, s))) return rc0;  // drain the dealing pipeline of the previous seeding, if any
   hipLaunchKernelGGL(k_seed, dim3((h->P.B + 255) / 256), dim3(256), 0, s, h->P, (const uint64_t *)d_seeds, base_seed, 0,
@@ -538,10 +569,11 @@ int skyjo_vec_snapshot_create(skyjo_vec *h, skyjo_vec_snapshot **out, void *stre
   int rc;
   if ((rc = publish_deals(h, s))) return rc;  // no deal in flight: the arrays below are the whole truth
   HIPCHK(hipDeviceSynchronize());
+  if ((rc = dev_error_check(h))) return rc;   // (a voided run is not worth keeping)
   skyjo_vec_snapshot *sn = new (std::nothrow) skyjo_vec_snapshot();
   if (!sn) return fail(SKYJO_E_INVALID, "out of host memory");
-  sn->owner = h, sn->device_id = h->cfg.device_id;
-  for (auto &a : h->allocs) sn->bytes += (a.second + 255) & ~(size_t)255;
+  sn->owner = h, sn->owner_generation = h->generation, sn->device_id = h->cfg.device_id;
+  for (auto &a : h->allocs) sn->bytes += (a.second + 255) & ~(size_t)255, sn->array_bytes.push_back(a.second);
   if (hipMalloc(&sn->blob, sn->bytes) != hipSuccess) {
     delete sn;
     return fail(SKYJO_E_DEVICE, "hipMalloc failed for the snapshot");
@@ -556,7 +588,11 @@ int skyjo_vec_snapshot_create(skyjo_vec *h, skyjo_vec_snapshot **out, void *stre
     }
     off += (a.second + 255) & ~(size_t)255;
   }
-  HIPCHK(hipStreamSynchronize(s));
+  if (hipError_t e = hipStreamSynchronize(s); e != hipSuccess) {
+    (void)hipFree(sn->blob);
+    delete sn;
+    return fail(SKYJO_E_DEVICE, std::string("snapshot copy: ") + hipGetErrorString(e));
+  }
   sn->pending_iters = h->pending_iters, sn->deal_every_iters = h->deal_every_iters, sn->calm_runs = h->calm_runs;
   sn->list_sel = h->list_sel, sn->auto_interval = h->auto_interval, sn->health_seen = h->health_seen;
   sn->deal_tag = h->deal_tag, sn->iter = h->iter, sn->iters_total = h->iters_total;
@@ -567,18 +603,23 @@ int skyjo_vec_snapshot_create(skyjo_vec *h, skyjo_vec_snapshot **out, void *stre
 
 int skyjo_vec_snapshot_restore(skyjo_vec *h, const skyjo_vec_snapshot *sn, void *stream) {
   if (!h || !sn) return fail(SKYJO_E_INVALID, "null argument");
-  if (sn->owner != h) return fail(SKYJO_E_INVALID, "the snapshot was taken from another handle");
+  if (sn->owner != h || sn->owner_generation != h->generation)  // (a destroyed handle's address may have been reused)
+    return fail(SKYJO_E_INVALID, "the snapshot was taken from another handle");
+  // the blob is the handle's arrays in table order: the same count (or fewer: the host-style scratch may have been
+  // allocated since) of the same sizes
+  if (sn->array_bytes.size() > h->allocs.size()) return fail(SKYJO_E_INVALID, "the snapshot does not fit the handle's arrays");
+  for (size_t k = 0; k < sn->array_bytes.size(); k++)
+    if (sn->array_bytes[k] != h->allocs[k].second) return fail(SKYJO_E_INVALID, "the snapshot does not fit the handle's arrays");
   GUARD(h);
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if ((rc = publish_deals(h, s))) return rc;
   HIPCHK(hipDeviceSynchronize());
-  size_t off = 0, n = 0;
-  for (auto &a : h->allocs) {  // (arrays allocated after the snapshot - the host-style scratch - are not part of it)
-    const size_t padded = (a.second + 255) & ~(size_t)255;
-    if (off + padded > sn->bytes) break;
+  size_t off = 0;
+  for (size_t k = 0; k < sn->array_bytes.size(); k++) {  // (arrays allocated after the snapshot are not part of it)
+    const auto &a = h->allocs[k];
     HIPCHK(hipMemcpyAsync(a.first, (const uint8_t *)sn->blob + off, a.second, hipMemcpyDeviceToDevice, s));
-    off += padded, n++;
+    off += (a.second + 255) & ~(size_t)255;
   }
   HIPCHK(hipStreamSynchronize(s));
   h->pending_iters = sn->pending_iters, h->deal_every_iters = sn->deal_every_iters, h->calm_runs = sn->calm_runs;
@@ -620,16 +661,65 @@ int skyjo_vec_reset(skyjo_vec *h, const uint8_t *mask, void *records_out, void *
   return publish_deals(h, s);
 }
 
+static int step_once(skyjo_vec *h, const int32_t *actions, void *records_out, double *end_rew, uint8_t *end_flag, hipStream_t s) {
+  const bool due = h->pending_iters + 1 >= h->deal_every_iters, piped = piped_mode(h);
+  if (due && piped) plan_cycle(h);
+  int rc = launch_step(h, s, false, actions, (uint8_t *)records_out, nullptr, 1, 0, end_rew, end_flag);
+  if (rc) return rc;
+  if (due) return piped ? start_deals_piped(h, s) : start_deals(h, s);
+  return SKYJO_OK;
+}
+
 int skyjo_vec_step(skyjo_vec *h, const int32_t *actions, void *records_out, void *stream) {
   if (!h || !actions) return fail(SKYJO_E_INVALID, "null argument");
   GUARD(h);
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  return step_once(h, actions, records_out, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int skyjo_vec_step_collect(skyjo_vec *h, const int32_t *actions, void *records_out, double *final_rewards_out,
+                           uint8_t *episode_end_out, void *stream) {
+  if (!h || !actions || !final_rewards_out || !episode_end_out) return fail(SKYJO_E_INVALID, "null argument");
+  GUARD(h);
+  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  return step_once(h, actions, records_out, final_rewards_out, episode_end_out, (hipStream_t)stream);
+}
+
+int skyjo_vec_model_rollout(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, int32_t T, uint64_t seed,
+                            uint64_t first_ticket, int32_t no_masking, const skyjo_vec_rollout_buffers *b, void *stream) {
+  if (!h || !policy || !b || T < 0 || !b->records || !b->actions) return fail(SKYJO_E_INVALID, "skyjo_vec_model_rollout: bad argument");
+  if (value && !b->values) return fail(SKYJO_E_INVALID, "skyjo_vec_model_rollout: a value net needs a values buffer");
+  if ((b->final_rewards == nullptr) != (b->episode_end == nullptr))
+    return fail(SKYJO_E_INVALID, "skyjo_vec_model_rollout: final_rewards and episode_end go together");
+  GUARD(h);
+  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  if (policy->net.out_dim != SKYJO_NUM_ACTIONS) return fail(SKYJO_E_INVALID, "the policy net needs 26 outputs");
+  if (policy->device_id != h->cfg.device_id || policy->obs_dim != h->P.L.D || !h->P.L.indirect)
+    return fail(SKYJO_E_INVALID, "the policy net must live on the engine's device and take the engine's (indirect) observation");
+  if (value && (policy->obs_dim != value->obs_dim || policy->device_id != value->device_id || policy->net.split != value->net.split))
+    return fail(SKYJO_E_INVALID, "policy and value net must share the observation size, the precision and the device");
   hipStream_t s = (hipStream_t)stream;
-  const bool due = h->pending_iters + 1 >= h->deal_every_iters, piped = piped_mode(h);
-  if (due && piped) plan_cycle(h);
-  int rc = launch_step(h, s, false, actions, (uint8_t *)records_out, nullptr, 1, 0);
-  if (rc) return rc;
-  if (due) return piped ? start_deals_piped(h, s) : start_deals(h, s);
+  const size_t B = (size_t)h->P.B, rb = (size_t)h->P.L.rec_bytes, N = (size_t)h->P.L.N;
+  const size_t vd = value ? (size_t)value->net.out_dim : 0;
+  uint8_t *rec = (uint8_t *)b->records;
+  int rc;
+  for (int t = 0; t < T; t++) {
+    SkMlpDraw d{};
+    d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = first_ticket + (uint64_t)t;
+    d.game_id0 = h->P.game_id0, d.actions = b->actions + (size_t)t * B, d.logp = b->logp ? b->logp + (size_t)t * B : nullptr;
+    if ((rc = launch_mlp(policy->net, value ? value->net : policy->net, value ? 2 : 1, rec + (size_t)t * B * rb, (int)rb, policy->obs_dim,
+                         (int64_t)B, nullptr, d, value ? b->values + (size_t)t * B * vd : nullptr, s)))
+      return rc;
+    if ((rc = step_once(h, b->actions + (size_t)t * B, rec + (size_t)(t + 1) * B * rb,
+                        b->final_rewards ? b->final_rewards + (size_t)t * B * N : nullptr, b->episode_end ? b->episode_end + (size_t)t * B : nullptr, s)))
+      return rc;
+  }
+  if (value) {  // the bootstrap value of the records the rollout ends on
+    SkMlpDraw nodraw{};
+    if ((rc = launch_mlp(value->net, value->net, 1, rec + (size_t)T * B * rb, (int)rb, value->obs_dim, (int64_t)B, b->values + (size_t)T * B * vd, nodraw,
+                         nullptr, s)))
+      return rc;
+  }
   return SKYJO_OK;
 }
 
@@ -703,11 +793,12 @@ int skyjo_vec_sample_actions(skyjo_vec *h, const void *records, const float *log
   return SKYJO_OK;
 }
 
-int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, const float *w1, const float *b1,
+int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, int32_t precision, const float *w1, const float *b1,
                          const float *w2, const float *b2, const float *w3, const float *b3, skyjo_vec_mlp **out) {
   if (!out || !w1 || !b1 || !w2 || !b2 || !w3 || !b3) return fail(SKYJO_E_INVALID, "null argument");
   if (obs_dim < 1 || obs_dim > SKP_IN - 1 || out_dim < 1 || out_dim > SKP_OUT)
     return fail(SKYJO_E_INVALID, "skyjo_vec_mlp: obs_dim must be 1..31 and out_dim 1..32");
+  if (precision != SKYJO_MLP_BF16 && precision != SKYJO_MLP_FP32) return fail(SKYJO_E_INVALID, "skyjo_vec_mlp: unknown precision");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return fail(SKYJO_E_INVALID, "device_id out of range");
   DevGuard guard_(device_id);
@@ -717,9 +808,17 @@ int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, co
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
   };
+  auto bf16_lo = [&](float f) {  // what the high half leaves over, again rounded to bf16: f = hi + lo to 16 significant bits
+    const uint32_t hi = (uint32_t)bf16(f) << 16;
+    float fh;
+    memcpy(&fh, &hi, 4);
+    return bf16(f - fh);
+  };
+  const bool split = precision == SKYJO_MLP_FP32;
   auto acc_k = [](int ks, int hh, int j) { return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * hh + (j & 3); };
   const int H = SKP_HIDDEN;
-  std::vector<uint16_t> f1((size_t)8 * 2 * 64 * 8), f2((size_t)8 * 16 * 64 * 8), f3((size_t)16 * 64 * 8);
+  const size_t e1 = (size_t)8 * 2 * 64 * 8, e2 = (size_t)8 * 16 * 64 * 8, e3 = (size_t)16 * 64 * 8;
+  std::vector<uint16_t> f1(e1), f2(e2), f3(e3), g1(split ? e1 : 0), g2(split ? e2 : 0), g3(split ? e3 : 0);
   std::vector<float> c2((size_t)8 * 64 * 16), c3((size_t)64 * 16);
   for (int u = 0; u < 8; u++)
     for (int l = 0; l < 64; l++) {
@@ -728,16 +827,28 @@ int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, co
         for (int j = 0; j < 8; j++) {
           const int k = 16 * s + 8 * hh + j;  // natural order: the kernel builds this operand from the record itself
           const float v = k < obs_dim ? w1[(size_t)m * obs_dim + k] : (k == SKP_IN - 1 ? b1[m] : 0.f);
-          f1[(((size_t)u * 2 + s) * 64 + l) * 8 + j] = bf16(v);
+          const size_t at = (((size_t)u * 2 + s) * 64 + l) * 8 + j;
+          f1[at] = bf16(v);
+          if (split) g1[at] = bf16_lo(v);
         }
       for (int ks = 0; ks < 16; ks++)
-        for (int j = 0; j < 8; j++) f2[(((size_t)u * 16 + ks) * 64 + l) * 8 + j] = bf16(w2[(size_t)m * H + acc_k(ks, hh, j)]);
+        for (int j = 0; j < 8; j++) {
+          const float v = w2[(size_t)m * H + acc_k(ks, hh, j)];
+          const size_t at = (((size_t)u * 16 + ks) * 64 + l) * 8 + j;
+          f2[at] = bf16(v);
+          if (split) g2[at] = bf16_lo(v);
+        }
       for (int r = 0; r < 16; r++) c2[((size_t)u * 64 + l) * 16 + r] = b2[32 * u + (r & 3) + 8 * (r >> 2) + 4 * hh];
     }
   for (int l = 0; l < 64; l++) {
     const int m = l & 31, hh = l >> 5;
     for (int ks = 0; ks < 16; ks++)
-      for (int j = 0; j < 8; j++) f3[((size_t)ks * 64 + l) * 8 + j] = m < out_dim ? bf16(w3[(size_t)m * H + acc_k(ks, hh, j)]) : 0;
+      for (int j = 0; j < 8; j++) {
+        const float v = m < out_dim ? w3[(size_t)m * H + acc_k(ks, hh, j)] : 0.f;
+        const size_t at = ((size_t)ks * 64 + l) * 8 + j;
+        f3[at] = bf16(v);
+        if (split) g3[at] = bf16_lo(v);
+      }
     for (int r = 0; r < 16; r++) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
       c3[(size_t)l * 16 + r] = row < out_dim ? b3[row] : 0.f;
@@ -745,24 +856,29 @@ int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, co
   }
   skyjo_vec_mlp *m = new skyjo_vec_mlp();
   m->device_id = device_id, m->obs_dim = obs_dim;
-  const size_t n1 = f1.size() * 2, n2 = f2.size() * 2, n3 = f3.size() * 2, nb2 = c2.size() * 4, nb3 = c3.size() * 4;
-  if (hipMalloc(&m->blob, n1 + n2 + n3 + nb2 + nb3) != hipSuccess) {
+  struct Piece { const void *src; size_t bytes; };
+  const Piece pieces[8] = {{f1.data(), e1 * 2}, {f2.data(), e2 * 2}, {f3.data(), e3 * 2}, {c2.data(), c2.size() * 4}, {c3.data(), c3.size() * 4},
+                           {g1.data(), g1.size() * 2}, {g2.data(), g2.size() * 2}, {g3.data(), g3.size() * 2}};
+  size_t total = 0, offs[8];
+  for (int k = 0; k < 8; k++) offs[k] = total, total += (pieces[k].bytes + 255) & ~(size_t)255;
+  if (hipMalloc(&m->blob, total) != hipSuccess) {
     delete m;
     return fail(SKYJO_E_DEVICE, "hipMalloc failed for the packed weights");
   }
   uint8_t *p = (uint8_t *)m->blob;
-  hipError_t e = hipMemcpy(p, f1.data(), n1, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(p + n1, f2.data(), n2, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(p + n1 + n2, f3.data(), n3, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(p + n1 + n2 + n3, c2.data(), nb2, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(p + n1 + n2 + n3 + nb2, c3.data(), nb3, hipMemcpyHostToDevice);
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 8 && e == hipSuccess; k++)
+    if (pieces[k].bytes) e = hipMemcpy(p + offs[k], pieces[k].src, pieces[k].bytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     (void)hipFree(m->blob);
     delete m;
     return fail(SKYJO_E_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
   }
-  m->net.w1 = (const uint4 *)p, m->net.w2 = (const uint4 *)(p + n1), m->net.w3 = (const uint4 *)(p + n1 + n2);
-  m->net.b2 = (const float *)(p + n1 + n2 + n3), m->net.b3 = (const float *)(p + n1 + n2 + n3 + nb2);
+  m->net.w1 = (const uint4 *)(p + offs[0]), m->net.w2 = (const uint4 *)(p + offs[1]), m->net.w3 = (const uint4 *)(p + offs[2]);
+  m->net.b2 = (const float *)(p + offs[3]), m->net.b3 = (const float *)(p + offs[4]);
+  m->net.split = split ? 1 : 0;
+  m->net.w1l = split ? (const uint4 *)(p + offs[5]) : nullptr, m->net.w2l = split ? (const uint4 *)(p + offs[6]) : nullptr;
+  m->net.w3l = split ? (const uint4 *)(p + offs[7]) : nullptr;
   m->net.out_dim = out_dim;
   *out = m;
   return SKYJO_OK;
@@ -783,9 +899,7 @@ int skyjo_vec_mlp_forward(const skyjo_vec_mlp *m, const void *records, int32_t r
   if (n == 0) return SKYJO_OK;
   DevGuard guard_(m->device_id);
   SkMlpDraw nodraw{};
-  hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT * SKP_WG - 1) / (32 * SKP_GT * SKP_WG))), dim3(64 * SKP_WG), 0, (hipStream_t)stream, m->net,
-                     (const uint8_t *)records, (int)record_bytes, m->obs_dim, (long long)n, out, nodraw, m->net, (float *)nullptr);
-  HIPCHK(hipGetLastError());
+  return launch_mlp(m->net, m->net, 1, (const uint8_t *)records, (int)record_bytes, m->obs_dim, n, out, nodraw, nullptr, (hipStream_t)stream);
   return SKYJO_OK;
 }
 
@@ -798,10 +912,7 @@ int skyjo_vec_mlp_act(skyjo_vec *h, const skyjo_vec_mlp *m, const void *records,
   SkMlpDraw d{};
   d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = ticket;
   d.game_id0 = h->P.game_id0, d.actions = actions_out, d.logp = logp_out;
-  hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT * SKP_WG - 1) / (32 * SKP_GT * SKP_WG))), dim3(64 * SKP_WG), 0, (hipStream_t)stream, m->net,
-                     (const uint8_t *)records, (int)h->P.L.rec_bytes, m->obs_dim, (long long)n, logits_out, d, m->net, (float *)nullptr);
-  HIPCHK(hipGetLastError());
-  return SKYJO_OK;
+  return launch_mlp(m->net, m->net, 1, (const uint8_t *)records, (int)h->P.L.rec_bytes, m->obs_dim, n, logits_out, d, nullptr, (hipStream_t)stream);
 }
 
 int skyjo_vec_mlp_act_value(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, const void *records, int64_t n,
@@ -811,17 +922,15 @@ int skyjo_vec_mlp_act_value(skyjo_vec *h, const skyjo_vec_mlp *policy, const sky
     return fail(SKYJO_E_INVALID, "skyjo_vec_mlp_act_value: bad argument");
   GUARD(h);
   if (policy->net.out_dim != SKYJO_NUM_ACTIONS) return fail(SKYJO_E_INVALID, "the policy net needs 26 outputs");
-  if (policy->obs_dim != value->obs_dim || policy->device_id != value->device_id || policy->device_id != h->cfg.device_id)
-    return fail(SKYJO_E_INVALID, "policy and value net must share the observation size and the engine's device");
+  if (policy->obs_dim != value->obs_dim || policy->device_id != value->device_id || policy->device_id != h->cfg.device_id ||
+      policy->net.split != value->net.split)
+    return fail(SKYJO_E_INVALID, "policy and value net must share the observation size, the precision and the engine's device");
   if (n == 0) return SKYJO_OK;
   SkMlpDraw d{};
   d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = ticket;
   d.game_id0 = h->P.game_id0, d.actions = actions_out, d.logp = logp_out;
-  hipLaunchKernelGGL(k_mlp_forward, dim3((unsigned)((n + 32 * SKP_GT * SKP_WG - 1) / (32 * SKP_GT * SKP_WG)), 2), dim3(64 * SKP_WG), 0, (hipStream_t)stream,
-                     policy->net, (const uint8_t *)records, (int)h->P.L.rec_bytes, policy->obs_dim, (long long)n, logits_out, d,
-                     value->net, values_out);
-  HIPCHK(hipGetLastError());
-  return SKYJO_OK;
+  return launch_mlp(policy->net, value->net, 2, (const uint8_t *)records, (int)h->P.L.rec_bytes, policy->obs_dim, n, logits_out, d, values_out,
+                    (hipStream_t)stream);
 }
 
 int skyjo_vec_episode_ends(skyjo_vec *h, const void *records, double *final_rewards_out, uint8_t *episode_end_out, void *stream) {
@@ -842,14 +951,16 @@ int skyjo_vec_get_counters(skyjo_vec *h, skyjo_vec_counters *out, void *stream) 
   hipLaunchKernelGGL(k_reduce_stats, dim3(64), dim3(256), 0, s, h->P);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, h->P.counters, sizeof(SkCounters), hipMemcpyDeviceToHost, s));
-  uint32_t err = 0;
-  HIPCHK(hipMemcpyAsync(&err, h->P.dev_error, sizeof(err), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   out->iters = h->iters_total;
-  if (err & SK_ERR_DEAL_TIMEOUT)
-    return fail(SKYJO_E_DEVICE, "a step kernel gave up waiting for the dealing kernel that should run beside it (SKYJO_OPT_OVERLAP): "
-                                "results since then are void; switch the option off or re-seed");
-  return SKYJO_OK;
+  return dev_error_check(h);
+}
+
+int skyjo_vec_check_error(skyjo_vec *h, void *stream) {
+  if (!h) return fail(SKYJO_E_INVALID, "null handle");
+  GUARD(h);
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return dev_error_check(h);
 }
 
 int skyjo_vec_reset_counters(skyjo_vec *h, void *stream) {
@@ -903,7 +1014,7 @@ int skyjo_vec_get_state(skyjo_vec *h, int32_t game, skyjo_game_state *o, void *s
                             hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
   }
-  return SKYJO_OK;
+  return dev_error_check(h);
 }
 
 int skyjo_vec_set_state(skyjo_vec *h, int32_t game, const skyjo_game_state *in, void *stream) {
@@ -1080,7 +1191,7 @@ int skyjo_vec_step_host(skyjo_vec *h, const int32_t *actions_host, void *records
     HIPCHK(hipMemcpy(records_out_host, h->d_records, (size_t)h->P.B * h->P.L.rec_bytes, hipMemcpyDeviceToHost));
   else
     HIPCHK(hipStreamSynchronize(nullptr));
-  return SKYJO_OK;
+  return dev_error_check(h);
 }
 
 int skyjo_vec_observe_host(skyjo_vec *h, const int32_t *players_host, void *records_out_host) {
@@ -1092,7 +1203,7 @@ int skyjo_vec_observe_host(skyjo_vec *h, const int32_t *players_host, void *reco
     HIPCHK(hipMemcpy(h->d_actions, players_host, sizeof(int32_t) * (size_t)h->P.B, hipMemcpyHostToDevice));
   if ((rc = skyjo_vec_observe(h, players_host ? h->d_actions : nullptr, h->d_records, nullptr))) return rc;
   HIPCHK(hipMemcpy(records_out_host, h->d_records, (size_t)h->P.B * h->P.L.rec_bytes, hipMemcpyDeviceToHost));
-  return SKYJO_OK;
+  return dev_error_check(h);
 }
 
 int skyjo_vec_reset_host(skyjo_vec *h, const uint8_t *mask_host, void *records_out_host) {
@@ -1106,7 +1217,7 @@ int skyjo_vec_reset_host(skyjo_vec *h, const uint8_t *mask_host, void *records_o
     HIPCHK(hipMemcpy(records_out_host, h->d_records, (size_t)h->P.B * h->P.L.rec_bytes, hipMemcpyDeviceToHost));
   else
     HIPCHK(hipStreamSynchronize(nullptr));
-  return SKYJO_OK;
+  return dev_error_check(h);
 }
 
 int skyjo_vec_get_rewards_host(skyjo_vec *h, double *rewards_out, double *scores_out, uint8_t *done_out) {
@@ -1116,7 +1227,7 @@ int skyjo_vec_get_rewards_host(skyjo_vec *h, double *rewards_out, double *scores
   if (rewards_out) HIPCHK(hipMemcpy(rewards_out, h->P.rewards, n * sizeof(double), hipMemcpyDeviceToHost));
   if (scores_out) HIPCHK(hipMemcpy(scores_out, h->P.scores, n * sizeof(double), hipMemcpyDeviceToHost));
   if (done_out) HIPCHK(hipMemcpy(done_out, h->P.done, (size_t)h->P.B, hipMemcpyDeviceToHost));
-  return SKYJO_OK;
+  return dev_error_check(h);
 }
 
 int skyjo_dev_malloc(int device_id, size_t bytes, void **out) {

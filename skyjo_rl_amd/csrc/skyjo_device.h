@@ -69,7 +69,7 @@ struct SkParams {
   uint32_t *deal_ep;        // [2][tiles*64] episode index of each listed deal
   uint32_t *deal_count;     // [2]
   uint32_t *bank_empty;     // [2] games whose bank held no episode when the last scan looked (early warning of a drain); [1]: see k_deal
-  volatile uint32_t *health_host;  // [2] host-mapped: {that count, dealing-run tag} - written once per run, read by the host
+  volatile uint32_t *health_host;  // [4] host-mapped: {that count, dealing-run tag} - written once per run, read by the host; [2] = SK_ERR_* (sticky)
   uint32_t *mt;             // [tiles*64][624] numpy-legacy MT19937 state, advanced in place (mt_untwist steps it back)
   int32_t *mt_idx;          // [1+SK_BANK][tiles*64]: [0] stream position (idx | ahead << 16), [1 + slot] position before its deal
   uint64_t *seeds;          // [tiles*64] value given to set_seed
@@ -466,22 +466,30 @@ __device__ __forceinline__ void reshuffle_discard(const SkParams &P, uint8_t *lp
 // While a dealing launch overlaps this kernel, the games it deals for are marked busy: it owns their RNG stream
 // and one bank slot.  The rare paths that need the stream wait for that one deal to finish (the dealing launch
 // never waits for anybody, so this cannot deadlock; the spin is bounded all the same).
-// Returns true when that deal gave itself up (close to a full turn of the generator state, see k_deal): it then left no record and no trace in the stream.
-__device__ __forceinline__ bool wait_deal_done(const SkParams &P, int g) {
+// Returns SK_WAIT_OK when that deal is finished, SK_WAIT_GAVE_UP when it gave itself up (close to a full turn of the generator
+// state, see k_deal: it then left no record and no trace in the stream), SK_WAIT_TIMEOUT when the dealing launch never showed
+// up (it is not resident beside this kernel and this kernel cannot end before it starts).  After a timeout the dealing
+// kernel may still be writing the game's stream: the caller must leave the stream and the bank slot alone and freeze the
+// game (sk_freeze); the sticky error words make every later host call on the handle fail until it is re-seeded.
+#define SK_WAIT_OK 0
+#define SK_WAIT_GAVE_UP 1
+#define SK_WAIT_TIMEOUT 2
+__device__ __forceinline__ int wait_deal_done(const SkParams &P, int g) {
   uint32_t f = 0;
   const uint32_t tag = P.plan_tag[g];  // the run that owns the game's busy slot (written on this stream, before this kernel or by this lane)
+  if (__hip_atomic_load(P.dev_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SK_ERR_DEAL_TIMEOUT) return SK_WAIT_TIMEOUT;  // (already given up: do not spin again)
   for (int spin = 0; spin < (1 << P.spin_log2); spin++) {
     f = __hip_atomic_load(&P.done_flag[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((f & 0x7fffffffu) == tag) break;
     __builtin_amdgcn_s_sleep(32);
   }
   if ((f & 0x7fffffffu) != tag) {
-    // The dealing launch never showed up (it is not resident beside this kernel and this kernel cannot end before it
-    // starts): give up loudly.  The sticky word makes skyjo_vec_get_counters fail; results after this point are void.
     atomicOr(P.dev_error, SK_ERR_DEAL_TIMEOUT);
+    P.health_host[2] = SK_ERR_DEAL_TIMEOUT;  // (host-mapped: every synchronising host call looks at it)
+    return SK_WAIT_TIMEOUT;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  return (f >> 31) != 0;
+  return (f >> 31) != 0 ? SK_WAIT_GAVE_UP : SK_WAIT_OK;
 }
 
 // MT19937's in-place regeneration is invertible, so a deal that has to be taken back needs no log of the values it
@@ -519,7 +527,8 @@ __device__ __forceinline__ int mt_rollback(const SkParams &P, uint32_t *mt, int 
   return snap;
 }
 
-__device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *lp, uint8_t *fp, int g) {
+// Returns false - with nothing touched - when the game's stream cannot be had (wait_deal_done timed out).
+__device__ __forceinline__ bool reshuffle_dispatch(const SkParams &P, uint8_t *lp, uint8_t *fp, int g) {
   if (P.rng_mode == SKYJO_RNG_MT19937) {
     const size_t G = (size_t)P.tiles * SK_TILE;
     uint32_t *mt = P.mt + (size_t)g * 624;
@@ -530,7 +539,9 @@ __device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *l
     const bool inflight = busy && !P.cancel[g];  // (already cancelled = already finished and undone)
     bool undo_inflight = false;
     if (inflight) {  // a deal is in flight for this game: let it finish, then undo it as well
-      undo_inflight = !wait_deal_done(P, g);
+      const int w = wait_deal_done(P, g);
+      if (w == SK_WAIT_TIMEOUT) return false;
+      undo_inflight = w == SK_WAIT_OK;
       P.cancel[g] = 1;
     }
     int packed = P.mt_idx[g];
@@ -551,6 +562,7 @@ __device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *l
     r.open(P.seeds[g] + 1, *(uint32_t *)(lp + LIDX(H_EPISODE)), LB(H_RESH), 1u);
     reshuffle_discard(P, lp, r);
   }
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -819,7 +831,11 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
     if (from_pile && nd == 0) {  // rare: works on the LDS copy of the header
       HDR_FLUSH(h);
 #ifndef SK_EXP_NO_RARE
-      reshuffle_dispatch(P, lp, fp, g);
+      if (SK_RARE(!reshuffle_dispatch(P, lp, fp, g))) {  // device error (sticky): the game is frozen, nothing was drawn
+        h.w0 = (h.w0 & 0x0000ffffu) | ((((h.w0 >> 16) & 0xffu) | F_DONE) << 16) | ((uint32_t)SKYJO_ST_ERROR << 24);
+        P.done[g] = 1;
+        return;
+      }
 #endif
       HDR_LOAD(h);
       cnt.reshuffles++;
@@ -1050,7 +1066,8 @@ __device__ __forceinline__ constexpr int sk_stage_stride(int rec_bytes) { return
 // Fallback when the pre-dealt episode is not available inside a launch (a mid-game reshuffle just
 // invalidated it, or the game already took one in this launch): deal right here, on this lane, from
 // the game's current stream position.  Rare and slow (one lane active), never changes results.
-__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane, int head);
+// Returns false - stream, bank and record untouched - when the game's stream cannot be had (wait_deal_done timed out).
+__device__ __forceinline__ bool deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane, int head);
 
 // ------------------------------------------------------------------------------------------
 // k_step: `iters` lockstep iterations over all tiles.  POLICY=false: one iteration with the
@@ -1122,7 +1139,8 @@ __device__ __forceinline__ void sk_plan_deals(const SkParams &P, int g) {
 
 template <bool INDIRECT, bool POLICY, int NP>
 __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *actions, uint8_t *rec_out,
-                                                  int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0) {
+                                                  int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0,
+                                                  double *end_rew_out, uint8_t *end_out) {
   SkParams P = Pin;
   if (NP > 0) P.L = sk_make_layout(NP, INDIRECT ? 1 : 0);  // same values as the host computed, now constants
   extern __shared__ uint32_t lds_raw[];
@@ -1177,8 +1195,10 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
       const bool over = ((h.w0 >> 16) & F_DONE) != 0;
       if (!POLICY) a = actions[g];
       const bool skip = !POLICY && a == SKYJO_ACTION_SKIP;
+      const bool acted = !over && !skip;  // this iteration applies (or refuses) an action of this game
       SpareRegs sp;
-      const bool resetting = over && P.auto_reset && !skip;
+      const bool frozen = (h.w0 >> 24) == SKYJO_ST_ERROR;  // (device error: stays as it is until the handle is re-seeded)
+      const bool resetting = over && P.auto_reset && !skip && !frozen;
       if (resetting) spare_issue(P, lp, lds_tile, tile, lane, g, sp);  // lands while the live games step
       if (!over && !skip) {
         const uint32_t v0 = ob.q0, v1 = ob.q1, v2 = ob.q2;  // the acting player's row, read for the previous record
@@ -1202,22 +1222,38 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
 #endif
       } else if (!skip) {
         a = -1;
-        if (P.auto_reset) {
+        if (resetting) {
+          bool dealt = true;
           if (!spare_commit(P, lp, g, sp)) {
 #ifndef SK_EXP_NO_RARE
-            deal_inline(P, lp, fp, g, tile, lane, sp.head);
+            dealt = deal_inline(P, lp, fp, g, tile, lane, sp.head);
 #endif
             cnt.waits++;  // counts the slow-path deals
           }
           HDR_LOAD(h);
-          h.w0 = (h.w0 & 0x00ffffffu) | ((uint32_t)SKYJO_ST_RESET << 24);
-          cnt.resets++;
-        } else {
+          if (SK_OFTEN(dealt)) {
+            h.w0 = (h.w0 & 0x00ffffffu) | ((uint32_t)SKYJO_ST_RESET << 24);
+            cnt.resets++;
+          } else {  // device error (sticky): the slot holds a stale record - frozen as a finished game
+            h.w0 = (h.w0 & 0x0000ffffu) | (((uint32_t)F_VALID | F_DONE) << 16) | ((uint32_t)SKYJO_ST_ERROR << 24);
+          }
+        } else if (!frozen) {
           h.w0 = (h.w0 & 0x00ffffffu) | ((uint32_t)SKYJO_ST_NOOP_DONE << 24);
         }
         STAMP(1);
       } else {
         a = -1;
+      }
+      // byte D of the record: a caller's action outside 0 .. 25 (refused: status ILLEGAL) is written as -2, so that it can
+      // neither read as "none" (-1) nor alias a legal action
+      if (!POLICY && acted && (unsigned)a >= (unsigned)SKYJO_NUM_ACTIONS) a = -2;
+      if (!POLICY && end_out) {
+        // rollout collection: the lane that ends an episode - by its natural end or by an illegal move - says so
+        // and hands out the final rewards of skyjo_env.py:293-312 it has just computed; zeros everywhere else.  A game that is
+        // only re-dealt, left alone (SKYJO_ACTION_SKIP) or already over does not end anything.
+        const bool end = acted && ((h.w0 >> 16) & F_DONE) != 0;
+        end_out[g] = end ? 1 : 0;
+        for (int q = 0; q < P.L.N; q++) end_rew_out[(size_t)g * P.L.N + q] = end ? P.rewards[(size_t)g * P.L.N + q] : 0.0;
       }
       // One read of the expected player's row serves this record and the next iteration's turn.  A draw leaves both the
       // player and his row as they were (the phase is 1 after an applied draw, 0 after a place, a reset or the final draw).
@@ -1332,7 +1368,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
     // a lane whose deal is still under way waits for it - the one place where this stream waits for the other, and only
     // for as long as the dealing kernel really needs beyond this launch.)
     if (P.ov_flags & 1u) {
-      if (P.busy[g]) (void)wait_deal_done(P, g);
+      if (P.busy[g]) (void)wait_deal_done(P, g);  // (after a timeout the deal stays busy: sk_publish_deals looks at its flag again)
       sk_publish_deals(P, g);
     }
     sk_plan_deals(P, g);
@@ -1393,8 +1429,9 @@ __global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *ma
   tile_load(P, P.state, tile, lane, lp);
   if (want) {
     const int head = P.bank_head[g] % SK_BANK;
-    if (!consume_spare(P, lp, tile, lane, g, head)) deal_inline(P, lp, fp, g, tile, lane, head);
+    const bool dealt = consume_spare(P, lp, tile, lane, g, head) || deal_inline(P, lp, fp, g, tile, lane, head);
     LB(H_STATUS) = SKYJO_ST_RESET;
+    if (!dealt) LB(H_FLAGS) |= F_DONE, LB(H_STATUS) = SKYJO_ST_ERROR;  // device error (sticky): frozen as it is
   }
   HdrRegs h;
   HDR_LOAD(h);
@@ -1925,21 +1962,24 @@ __device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rn
   refresh_minima(P, lp);
 }
 
-__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane, int head) {
+__device__ __forceinline__ bool deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane, int head) {
   const uint32_t ep = P.deals_consumed[g];
   const int busy = P.busy[g];
   if (busy) {
     // The bank is empty, but the dealing launch that overlaps this kernel is dealing exactly the episode needed
     // (slot `head`, the next in stream order) - unless a reshuffle already rolled that deal back.
     const bool cancelled = P.cancel[g] != 0;
-    P.cancel[g] = 1;  // taken (or superseded) here: the publishing kernel must not mark the slot ready
     if (P.rng_mode == SKYJO_RNG_MT19937 && !cancelled) {  // the stream is shared: wait for that deal and take it
-      if (!wait_deal_done(P, g)) {
+      const int w = wait_deal_done(P, g);
+      if (w == SK_WAIT_TIMEOUT) return false;
+      P.cancel[g] = 1;  // taken here: the publishing kernel must not mark the slot ready
+      if (w == SK_WAIT_OK) {
         load_spare(P, lp, busy - 1, tile, lane);
         bank_advance(P, lp, g, head, ep);
-        return;
+        return true;
       }
     }  // Philox deals do not depend on a stream position (and a cancelled / overrun MT deal has finished): deal here
+    P.cancel[g] = 1;  // superseded: the publishing kernel must not mark the slot ready
   }
   if (P.rng_mode == SKYJO_RNG_MT19937) {
     MtStream<16> r;
@@ -1954,6 +1994,7 @@ __device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint
   LB(H_BANK) = (uint8_t)head;  // the bank is empty; its head pointer survives the new record
   P.deals_consumed[g] = ep + 1;
   P.done[g] = 0;
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2303,12 +2344,15 @@ __global__ __launch_bounds__(SK_SAMPLE_BLOCK) void k_sample(SkLayout L, const ui
 }
 
 // Rollout collection: from the records a step has just written, mark the games whose episode ended in that
-// step (done, and not the record of a reset) and copy their final rewards (skyjo_env.py:293-312) - zeros elsewhere.
+// step and copy their final rewards (skyjo_env.py:293-312) - zeros elsewhere.  (skyjo_vec_step_collect has the step kernel
+// do the same on its way: no extra launch.)
 __global__ void k_episode_ends(SkParams P, const uint8_t *rec, double *rew_out, uint8_t *end_out) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= P.B) return;
   const uint8_t *meta = rec + (size_t)g * P.L.rec_bytes + P.L.Dp + 26;  // agent, phase, done, status
-  const bool end = meta[2] != 0 && meta[3] != SKYJO_ST_RESET && meta[3] != SKYJO_ST_NOOP_DONE;
+  // done, and the step that wrote the record applied (or refused) an action: byte D is -1 for a game that was re-dealt,
+  // already over or left alone (SKYJO_ACTION_SKIP) - none of those ends an episode (again)
+  const bool end = meta[2] != 0 && (int8_t)rec[(size_t)g * P.L.rec_bytes + P.L.D] != -1;
   end_out[g] = end ? 1 : 0;
   for (int p = 0; p < P.L.N; p++) rew_out[(size_t)g * P.L.N + p] = end ? P.rewards[(size_t)g * P.L.N + p] : 0.0;
 }

@@ -40,6 +40,10 @@ struct SkMlpDev {
   const float *b2;   // [8][64 lanes][16 regs] bias of layer 2 in accumulator layout
   const float *b3;   // [1][64][16]
   int out_dim;
+  // float32-grade mode (SKYJO_MLP_FP32): every weight is the sum of two bf16 values, w = hi + lo; w1 / w2 / w3 above hold
+  // the high halves, these the low halves in the same fragment layout (k_mlp_forward_split)
+  int split;
+  const uint4 *w1l, *w2l, *w3l;
 };
 
 // tanh(x) = 1 - 2 / (e^(2x) + 1) on two values at a time: the multiply, the add and the final multiply-add are packed
@@ -72,6 +76,41 @@ __device__ __forceinline__ skp_bf16x8 skp_frag(const uint4 *p) {
   skp_bf16x8 r;
   __builtin_memcpy(&r, &q, 16);
   return r;
+}
+
+// What follows the last layer, for the 32 games of a wavefront: the outputs go to memory (out: float32 [n][out_dim], may be
+// null) and - policy branch - the masked categorical draw is made on the logits in registers (sk_draw_action).
+__device__ __forceinline__ void skp_finish(const skp_f32x16 &acc, const int lane, const long long g, const long long n, const int out_dim,
+                                           float *out, const SkMlpDraw &draw, const uint8_t *rec, const int rec_bytes) {
+  const int h = lane >> 5;
+  if (out && g < n) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < out_dim) out[g * out_dim + row] = acc[r];
+    }
+  }
+  if (draw.enable) {
+    // a game's 32 outputs sit in two lanes (this one and lane ^ 32: rows 4h .. 4h+3 of every block of 8): swap halves
+    float full[32];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float other = __shfl_xor(acc[r], 32, 64);
+      const int blk8 = r >> 2, i4 = r & 3;
+      full[8 * blk8 + i4] = h ? other : acc[r];      // rows 0..3 of the block belong to the h = 0 lane
+      full[8 * blk8 + 4 + i4] = h ? acc[r] : other;  // rows 4..7 to the h = 1 lane
+    }
+    if (h == 0 && g < n) {
+      const uint32_t *mp = (const uint32_t *)(rec + g * rec_bytes + draw.mask_offset);
+      uint32_t mw[7];
+#pragma unroll
+      for (int k = 0; k < 7; k++) mw[k] = mp[k];
+      float lp = 0.f;
+      draw.actions[g] = sk_draw_action(full, mw, draw.no_masking, draw.seed, draw.ticket, draw.game_id0 + (uint64_t)g,
+                                       draw.logp ? &lp : nullptr, nullptr);
+      if (draw.logp) draw.logp[g] = lp;
+    }
+  }
 }
 
 // One wavefront = SKP_GT column tiles of 32 games: every weight fragment that is loaded feeds SKP_GT independent MFMAs
@@ -193,34 +232,129 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(SKP
     for (int c = 0; c < SKP_GT; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, h2[c][ks], acc[c], 0, 0, 0);
   }
 #pragma unroll
-  for (int c = 0; c < SKP_GT; c++) {
-    if (out && g[c] < n) {
+  for (int c = 0; c < SKP_GT; c++) skp_finish(acc[c], lane, g[c], n, net.out_dim, out, draw, rec, rec_bytes);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The float32-grade form (SKYJO_MLP_FP32).  The reference evaluates RLlib's TorchFC in float32
+// (rlskyjo/models/action_mask_model.py:43-49); bf16 operands alone leave the logits 8e-2 away from it.  Here every operand
+// of every product is the sum of two bf16 values - w = w_hi + w_lo, h = h_hi + h_lo, 16 significant bits each - and a
+// product is three MFMAs into the same float32 accumulator, w_hi h_lo + w_lo h_hi + w_hi h_hi (w_lo h_lo, 2^-16 of the
+// product, is left out): the logits and values agree with the float32 module to 1e-4 (tests/test_gpu_policy_net.py) at
+// three times the matrix work of the bf16 form.  The observations are int8 and exact in one bf16, so layer 1 takes two.
+//   * The activations stay in the accumulator layout as before; h1 (hi and lo: 128 registers) is held for all of layer
+//     2, while h2 is never held: as soon as an output tile of layer 2 is through the tanh, its two k-steps of layer 3
+//     are accumulated (layer 3 rides inside layer 2's loop), so the kernel keeps to 256 registers and two wavefronts
+//     per SIMD.
+//   * The 256 x 256 layer is 256 KB now (hi + lo) against 160 KB of LDS: the workgroup stages it in two halves of four
+//     output tiles (hi + lo: 128 KB), with a barrier either side of the reload.
+// tanh: the same v_exp_f32 / v_rcp_f32 form as above (1 ulp each: 2e-7 absolute on a value in [-1, 1]).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void skp_split8(const skp_f32x16 &a, int s, bool act, skp_bf16x8 &hi, skp_bf16x8 &lo) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < net.out_dim) out[g[c] * net.out_dim + row] = acc[c][r];
-      }
+  for (int j = 0; j < 8; j += 2) {
+    skp_f32x2 v = {a[8 * s + j], a[8 * s + j + 1]};
+    if (act) v = skp_tanh2(v);
+    const __bf16 h0 = (__bf16)v.x, h1 = (__bf16)v.y;
+    hi[j] = h0, hi[j + 1] = h1;
+    lo[j] = (__bf16)(v.x - (float)h0), lo[j + 1] = (__bf16)(v.y - (float)h1);
+  }
+}
+#define SKP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+__global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(SKP_WAVES, SKP_WAVES))) void k_mlp_forward_split(
+    SkMlpDev net_a, const uint8_t *rec, int rec_bytes, int obs_dim, long long n, float *out_a, SkMlpDraw draw_a, SkMlpDev net_b, float *out_b) {
+  __shared__ uint4 w2s[8 * 16 * 64];  // [4 tiles of this half][hi, lo][16 k-steps][64 lanes]
+  const bool second = blockIdx.y == 1;
+  const SkMlpDev net = second ? net_b : net_a;
+  float *out = second ? out_b : out_a;
+  SkMlpDraw draw = draw_a;
+  draw.enable = second ? 0 : draw_a.enable;
+  const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+  const long long g = ((long long)blockIdx.x * SKP_WG + (threadIdx.x >> 6)) * 32 + col;
+  // ---- input fragments (exact in bf16) ----
+  skp_bf16x8 x[2];
+  {
+    uint32_t ob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (g < n) {
+      const uint4 *r = (const uint4 *)(rec + g * rec_bytes);
+      const uint4 a = r[0], b = r[1];
+      ob[0] = a.x, ob[1] = a.y, ob[2] = a.z, ob[3] = a.w, ob[4] = b.x, ob[5] = b.y, ob[6] = b.z, ob[7] = b.w;
     }
-    if (draw.enable) {
-      // a game's 32 outputs sit in two lanes (this one and lane ^ 32: rows 4h .. 4h+3 of every block of 8): swap halves
-      float full[32];
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const float other = __shfl_xor(acc[c][r], 32, 64);
-        const int blk8 = r >> 2, i4 = r & 3;
-        full[8 * blk8 + i4] = h ? other : acc[c][r];      // rows 0..3 of the block belong to the h = 0 lane
-        full[8 * blk8 + 4 + i4] = h ? acc[c][r] : other;  // rows 4..7 to the h = 1 lane
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int k0 = 16 * s + j, k1 = 16 * s + 8 + j;
+        const float v0 = k0 < obs_dim ? (float)(int8_t)(ob[k0 >> 2] >> ((k0 & 3) * 8)) : (k0 == SKP_IN - 1 ? 1.0f : 0.0f);
+        const float v1 = k1 < obs_dim ? (float)(int8_t)(ob[k1 >> 2] >> ((k1 & 3) * 8)) : (k1 == SKP_IN - 1 ? 1.0f : 0.0f);
+        x[s][j] = (__bf16)(h ? v1 : v0);
       }
-      if (h == 0 && g[c] < n) {
-        const uint32_t *mp = (const uint32_t *)(rec + g[c] * rec_bytes + draw.mask_offset);
-        uint32_t mw[7];
+  }
+  // ---- layer 1: (hi + lo) weights x exact inputs ----
+  skp_bf16x8 h1h[16], h1l[16];
 #pragma unroll
-        for (int k = 0; k < 7; k++) mw[k] = mp[k];
-        float lp = 0.f;
-        draw.actions[g[c]] = sk_draw_action(full, mw, draw.no_masking, draw.seed, draw.ticket, draw.game_id0 + (uint64_t)g[c],
-                                            draw.logp ? &lp : nullptr, nullptr);
-        if (draw.logp) draw.logp[g[c]] = lp;
+  for (int u = 0; u < 8; u++) {
+    skp_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      acc = SKP_MFMA(skp_frag(net.w1l + (u * 2 + s) * 64 + lane), x[s], acc);
+      acc = SKP_MFMA(skp_frag(net.w1 + (u * 2 + s) * 64 + lane), x[s], acc);
+    }
+    skp_split8(acc, 0, true, h1h[2 * u], h1l[2 * u]);
+    skp_split8(acc, 1, true, h1h[2 * u + 1], h1l[2 * u + 1]);
+  }
+  // ---- layers 2 and 3 ----
+  skp_f32x16 acc3;
+  {
+    const float4 *bp = (const float4 *)(net.b3 + (size_t)lane * 16);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float4 b = bp[q];
+      acc3[4 * q] = b.x, acc3[4 * q + 1] = b.y, acc3[4 * q + 2] = b.z, acc3[4 * q + 3] = b.w;
+    }
+  }
+#pragma unroll 1
+  for (int half = 0; half < 2; half++) {
+    __syncthreads();  // (everybody is through with the previous half)
+    for (int i = threadIdx.x; i < 4 * 16 * 64; i += 64 * SKP_WG) {
+      const int t = i >> 10, r = i & 1023;  // tile of this half, (k-step, lane)
+      w2s[(2 * t) * 1024 + r] = net.w2[(size_t)(4 * half + t) * 1024 + r];
+      w2s[(2 * t + 1) * 1024 + r] = net.w2l[(size_t)(4 * half + t) * 1024 + r];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < 4; t++) {
+      const int u = 4 * half + t;
+      skp_f32x16 acc;
+      {
+        const float4 *bp = (const float4 *)(net.b2 + ((size_t)u * 64 + lane) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float4 b = bp[q];
+          acc[4 * q] = b.x, acc[4 * q + 1] = b.y, acc[4 * q + 2] = b.z, acc[4 * q + 3] = b.w;
+        }
+      }
+      const uint4 *wh = w2s + (2 * t) * 1024 + lane, *wl = wh + 1024;
+#pragma unroll
+      for (int ks = 0; ks < 16; ks++) {
+        const skp_bf16x8 a_hi = skp_frag(wh + ks * 64), a_lo = skp_frag(wl + ks * 64);
+        acc = SKP_MFMA(a_hi, h1l[ks], acc);
+        acc = SKP_MFMA(a_lo, h1h[ks], acc);
+        acc = SKP_MFMA(a_hi, h1h[ks], acc);
+      }
+      // this tile's 32 hidden units are k-steps 2u and 2u + 1 of layer 3
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        skp_bf16x8 h2h, h2l;
+        skp_split8(acc, s, true, h2h, h2l);
+        const skp_bf16x8 a_hi = skp_frag(net.w3 + (2 * u + s) * 64 + lane), a_lo = skp_frag(net.w3l + (2 * u + s) * 64 + lane);
+        acc3 = SKP_MFMA(a_hi, h2l, acc3);
+        acc3 = SKP_MFMA(a_lo, h2h, acc3);
+        acc3 = SKP_MFMA(a_hi, h2h, acc3);
       }
     }
   }
+  skp_finish(acc3, lane, g, n, net.out_dim, out, draw, rec, rec_bytes);
 }

@@ -162,6 +162,10 @@ class SkyjoGame(object):
 
     @property
     def game_metrics(self):
+        """``final_score`` is typed as the reference types it WITHOUT numba (``numba.config.DISABLE_JIT`` - the mode its seeded
+        test pins and oracle/gen_golden.py records): np.float64 where a column counted, Python float where not.  With real
+        numba ``_evaluate_game`` is jitted and returns plain Python floats throughout; only the repr in ``render_table()``'s
+        "Results: {...}" line differs (tests/golden/render.npz holds the non-JIT text)."""
         s = self._state_now()
         final = False
         if s["is_terminated"]:

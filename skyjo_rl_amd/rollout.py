@@ -1,8 +1,9 @@
-"""PPO-style rollout collection for config 5, all on the GPU and all through the C ABI: per lockstep iteration
-ONE launch evaluates the policy branch with its masked categorical draw and the value branch on the matrix cores
-(``FusedNet.act(value_net=...)`` -> ``skyjo_vec_mlp_act_value``), ``skyjo_vec_step`` writes the next records straight into the
-buffer, and one small kernel (``skyjo_vec_episode_ends``) marks the episodes that ended and copies their final rewards - three
-launches per iteration, no torch kernel, no host traffic.  What a learner needs per step of the acting seat
+"""PPO-style rollout collection for config 5, all on the GPU and all behind ONE call of the C ABI
+(``skyjo_vec_model_rollout``): per lockstep iteration one launch evaluates the policy branch with its masked categorical draw
+and the value branch on the matrix cores, and the step kernel writes the next records straight into the buffer and - the lane
+that ends an episode - the episode-end flag and the final rewards: two launches per iteration, no torch kernel, no host code
+between them.  ``collect_stepwise`` is the same loop made one launch at a time from Python (``FusedNet.act(value_net=...)``,
+``skyjo_vec_step_collect``): same bits, used by the tests.  What a learner needs per step of the acting seat
 (``rlskyjo/models/train_model_simple_rllib.py:22-59`` has RLlib collect the same columns): observation / action mask (inside the
 records), action, log-probability, value estimate, the acting agent, done flags and - at episode ends - the final rewards of
 skyjo_env.py:293-312 for every seat.  ``RolloutBuffer.valid`` tells a learner which rows are transitions at all.
@@ -41,25 +42,37 @@ class RolloutBuffer:
         return self.views().done[: self.T] == 0
 
 
-@torch.no_grad()
-def collect(env, policy, value, buf, seed=0, first_ticket=0, first_records=None):
-    """Fill ``buf`` with T steps of the current policy.  ``policy`` / ``value``: ``FusedNet`` of the model's two
-    branches.  ``first_records``: the records the rollout starts from (default: ``env.observe()``).  Returns ``buf``."""
-    T = buf.T
-    L = _lib.load()
-    vp = lambda t: C.c_void_p(t.data_ptr())
+def _first(env, buf, first_records):
     if first_records is None:
         env.observe(out=buf.records[0])
     else:
         buf.records[0].copy_(first_records)
-    for t in range(T):
-        rec = buf.records[t]
-        policy.act(env, rec, seed=seed, ticket=first_ticket + t, actions=buf.actions[t], logp=buf.logp[t], value_net=value,
-                   values=buf.values[t])
-        env.step(buf.actions[t], out=buf.records[t + 1])
-        # a game that has just ended shows done = 1 in the record written by this step; its rewards stay valid until the
-        # reset that the next step performs
-        _lib.check(L.skyjo_vec_episode_ends(env._h, vp(buf.records[t + 1]), vp(buf.final_rewards[t]), vp(buf.episode_end[t]),
-                                            env._stream()))
-    value(buf.records[T], out=buf.values[T])
+
+
+@torch.no_grad()
+def collect(env, policy, value, buf, seed=0, first_ticket=0, first_records=None, no_masking=False):
+    """Fill ``buf`` with T steps of the current policy in one native call.  ``policy`` / ``value``: ``FusedNet`` of the
+    model's two branches.  ``first_records``: the records the rollout starts from (default: ``env.observe()``)."""
+    L = _lib.load()
+    vp = lambda t: t.data_ptr()
+    _first(env, buf, first_records)
+    b = _lib.RolloutBuffers(vp(buf.records), vp(buf.actions), vp(buf.logp), vp(buf.values), vp(buf.final_rewards), vp(buf.episode_end))
+    _lib.check(L.skyjo_vec_model_rollout(env._h, policy._h, value._h, buf.T, int(seed), int(first_ticket), 1 if no_masking else 0,
+                                         C.byref(b), env._stream()))
+    return buf
+
+
+@torch.no_grad()
+def collect_stepwise(env, policy, value, buf, seed=0, first_ticket=0, first_records=None):
+    """The same rollout, one launch at a time from Python (the net, then ``skyjo_vec_step_collect``): bit-identical columns."""
+    L = _lib.load()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    _first(env, buf, first_records)
+    for t in range(buf.T):
+        policy.act(env, buf.records[t], seed=seed, ticket=first_ticket + t, actions=buf.actions[t], logp=buf.logp[t],
+                   value_net=value, values=buf.values[t])
+        # a game that ends in this step has its flag and its final rewards written by the step kernel itself
+        _lib.check(L.skyjo_vec_step_collect(env._h, vp(buf.actions[t]), vp(buf.records[t + 1]), vp(buf.final_rewards[t]),
+                                            vp(buf.episode_end[t]), env._stream()))
+    value(buf.records[buf.T], out=buf.values[buf.T])
     return buf

@@ -211,6 +211,10 @@ class SkyjoVecEnv:
     def sync(self):
         _lib.check(self._L.skyjo_dev_sync(None))
 
+    def check_error(self):
+        """Synchronise and raise if the engine carries a sticky device error (include/skyjo_vec.h: skyjo_vec_check_error)."""
+        _lib.check(self._L.skyjo_vec_check_error(self._h, self._stream()))
+
     # ------------------------------------------------------------------ host style API
     def _host_records(self):
         return np.zeros((self.num_envs, self.record_bytes), dtype=np.uint8)
@@ -295,7 +299,7 @@ class SkyjoVecEnv:
         return int(v.value)
 
     def overlap(self):
-        """True when the dealing kernel runs on its own stream beside the step kernels (default below 41 000 games)."""
+        """True when the dealing kernel runs on its own stream beside the step kernels (default up to 768 tiles = 49 152 games)."""
         v = C.c_int64()
         _lib.check(self._L.skyjo_vec_get_option(self._h, 2, C.byref(v)))
         return bool(v.value)

@@ -1,10 +1,15 @@
-"""the policy net of config 5 on the matrix cores (skyjo_vec_mlp_forward, csrc/skyjo_policy.h) against
-torch.  Floating point - the kernel keeps weights and inter-layer activations in bf16 and accumulates in float32:
+"""the policy net of config 5 on the matrix cores (skyjo_vec_mlp_forward, csrc/skyjo_policy.h)
+against torch.  The reference's TorchFC is float32 (rlskyjo/models/action_mask_model.py:43-49, 58-74); north_star
+states no tolerance, the ones used here are written out:
+
+  precision "fp32" (the default of FusedNet; every operand a bf16 pair, three MFMAs per product, float32 accumulation):
+  * against the plain float32 module: max |diff| of logits / values <= 1e-4, mean <= 2e-5, and
+    mean KL(softmax fp32 || softmax kernel) <= 1e-7 - at 65 536 x 4 as well (test_config5_full_size_...).
+  precision "bf16" (single bf16 weights and inter-layer activations - the fast mode):
   * against a torch float32 emulation of exactly that arithmetic (bf16-rounded weights, activations rounded to bf16
     after tanh): max |diff| of the outputs < 2e-2 and mean |diff| < 2e-3 (what is left is the fast tanh, the order of
     the float32 sums and the bf16 roundings that flip because of them);
-  * against the plain float32 module: max |diff| < 8e-2, mean < 1e-2, and the action distributions agree
-    (mean KL(softmax fp32 || softmax kernel) < 1e-3)."""
+  * against the plain float32 module: max |diff| < 8e-2, mean < 1e-2, mean KL < 1e-3."""
 import numpy as np
 import pytest
 
@@ -26,8 +31,13 @@ def _emulate(seq, x):
     return h
 
 
-@pytest.mark.parametrize("N,B,branch", [(4, 8192, "policy"), (3, 1000, "policy"), (2, 33, "value"), (4, 65536, "value")])
-def test_policy_net_matches_torch(N, B, branch):
+TOL = {"fp32": dict(max=1e-4, mean=2e-5, kl=1e-7), "bf16": dict(max=8e-2, mean=1e-2, kl=1e-3)}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("N,B,branch", [(4, 8192, "policy"), (3, 1000, "policy"), (2, 33, "value"), (4, 65536, "value"),
+                                        (4, 65536, "policy")])
+def test_policy_net_matches_torch(N, B, branch, precision):
     import torch
 
     from skyjo_rl_amd import SkyjoVecEnv
@@ -41,7 +51,7 @@ def test_policy_net_matches_torch(N, B, branch):
         for p in model.parameters():
             p.mul_(1.5)
     seq = model.policy if branch == "policy" else model.value
-    net = FusedNet(seq)
+    net = FusedNet(seq, precision=precision)
     rec = env.reset()
     for t in range(5):
         rec = env.step(env.sample_actions(torch.zeros((B, 26), device="cuda"), rec, seed=1, ticket=t))
@@ -51,13 +61,16 @@ def test_policy_net_matches_torch(N, B, branch):
         emu = _emulate(seq, x)
         ref = seq(x)
     assert got.shape == ref.shape
-    d = (got - emu).abs()
-    assert float(d.max()) < 2e-2 and float(d.mean()) < 2e-3, (float(d.max()), float(d.mean()))
+    tol = TOL[precision]
+    if precision == "bf16":
+        d = (got - emu).abs()
+        assert float(d.max()) < 2e-2 and float(d.mean()) < 2e-3, (float(d.max()), float(d.mean()))
     d32 = (got - ref).abs()
-    assert float(d32.max()) < 8e-2 and float(d32.mean()) < 1e-2, (float(d32.max()), float(d32.mean()))
+    assert float(d32.max()) <= tol["max"] and float(d32.mean()) <= tol["mean"], (precision, float(d32.max()), float(d32.mean()))
     if branch == "policy":
-        kl = (torch.softmax(ref, -1) * (torch.log_softmax(ref, -1) - torch.log_softmax(got, -1))).sum(-1)
-        assert float(kl.mean()) < 1e-3
+        ref64, got64 = ref.double(), got.double()  # (a KL of 1e-7 is below float32's resolution of the log-softmax)
+        kl = (torch.softmax(ref64, -1) * (torch.log_softmax(ref64, -1) - torch.log_softmax(got64, -1))).sum(-1)
+        assert float(kl.mean()) <= tol["kl"], float(kl.mean())
     net.close()
     env.close()
 
@@ -110,14 +123,15 @@ def test_act_equals_forward_then_sample_bit_for_bit():
     env.close()
 
 
-def test_config5_full_size_policy_loop_against_float32_module():
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_config5_full_size_policy_loop_against_float32_module(precision):
     """BASELINE config 5 at full size - 65 536 four-player games, every action drawn by the action-mask model on the matrix
     cores (policy + value branch in ONE launch, skyjo_vec_mlp_act_value) - against the float32 torch module on the same
-    records with the same weights.  Stated tolerances of the bf16 kernel vs float32 (north_star states none; these are the
-    round-off of bf16 weights / activations, see DESIGN.md "Deliberate deviations"): logits max |diff| < 8e-2, mean < 1e-2,
-    mean KL(float32 || kernel) of the masked action distributions < 1e-3, values max |diff| < 8e-2; the drawn action is
-    legal everywhere, its stored log-probability equals the masked log-softmax of the kernel's own logits within 1e-5, no
-    illegal move in 300 iterations, episodes end and the two-launch form gives the same bits."""
+    records with the same weights.  Tolerances vs float32 (north_star states none; TOL above): "fp32" - logits and values
+    max |diff| <= 1e-4, mean <= 2e-5, mean KL(float32 || kernel) of the masked action distributions <= 1e-7; "bf16" - 8e-2 /
+    1e-2 / 1e-3.  The drawn action is legal everywhere, its stored log-probability equals the masked log-softmax of the
+    kernel's own logits within 1e-5, no illegal move in 300 iterations, episodes end and the two-launch form gives the same
+    bits."""
     import torch
 
     from skyjo_rl_amd import SkyjoVecEnv
@@ -128,7 +142,8 @@ def test_config5_full_size_policy_loop_against_float32_module():
     env = SkyjoVecEnv(B, num_players=N)
     env.seed(None, 17)
     model = ActionMaskModel(obs_dim=env.obs_dim).cuda()
-    pol, val = FusedNet(model.policy), FusedNet(model.value)
+    pol, val = FusedNet(model.policy, precision=precision), FusedNet(model.value, precision=precision)
+    tol = TOL[precision]
     rec = env.reset()
     act = torch.empty(B, dtype=torch.int32, device="cuda")
     logp = torch.empty(B, device="cuda")
@@ -144,11 +159,12 @@ def test_config5_full_size_policy_loop_against_float32_module():
                 ref = model.policy(x)
                 vref = model.value(x)
             d = (logits - ref).abs()
-            assert float(d.max()) < 8e-2 and float(d.mean()) < 1e-2, (t, float(d.max()), float(d.mean()))
-            assert float((values - vref).abs().max()) < 8e-2
+            assert float(d.max()) <= tol["max"] and float(d.mean()) <= tol["mean"], (t, float(d.max()), float(d.mean()))
+            assert float((values - vref).abs().max()) <= tol["max"]
             inf = torch.clamp(torch.log(mask), min=FLOAT_MIN)
-            kl = (torch.softmax(ref + inf, -1) * (torch.log_softmax(ref + inf, -1) - torch.log_softmax(logits + inf, -1))).sum(-1)
-            assert float(kl.mean()) < 1e-3
+            r64, l64, i64 = ref.double(), logits.double(), inf.double()
+            kl = (torch.softmax(r64 + i64, -1) * (torch.log_softmax(r64 + i64, -1) - torch.log_softmax(l64 + i64, -1))).sum(-1)
+            assert float(kl.mean()) <= tol["kl"], float(kl.mean())
             live = v.done == 0
             assert bool(v.action_mask.gather(1, act.long().unsqueeze(1)).squeeze(1).eq(1)[live].all())
             own = torch.log_softmax(logits + inf, -1).gather(1, act.long().unsqueeze(1)).squeeze(1)

@@ -11,7 +11,7 @@ def test_rollout_to_learner_and_back():
 
     from skyjo_rl_amd import SkyjoVecEnv
     from skyjo_rl_amd.action_mask_model import ActionMaskModel
-    from skyjo_rl_amd.ppo import compute_returns, ppo_update, repack
+    from examples.ppo import compute_returns, ppo_update, repack
     from skyjo_rl_amd.rollout import RolloutBuffer, collect
 
     torch.manual_seed(0)
@@ -55,8 +55,8 @@ def test_rollout_to_learner_and_back():
     pol, val = repack(model)                                          # updated weights back onto the matrix cores
     collect(env, pol, val, buf, seed=1, first_ticket=T)
     assert env.counters()["illegal"] == 0 and int(buf.episode_end.sum()) > 0
-    # the re-packed net is the updated torch module (bf16 tolerance of tests/test_gpu_policy_net.py)
+    # the re-packed net is the updated torch module (float32-grade tolerance of tests/test_gpu_policy_net.py)
     with torch.no_grad():
         ref = model.policy(buf.views().observations[5].to(torch.float32))
-    assert float((pol(buf.records[5]) - ref).abs().max()) < 8e-2
+    assert float((pol(buf.records[5]) - ref).abs().max()) < 1e-4
     pol.close(), val.close(), env.close()

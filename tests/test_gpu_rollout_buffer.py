@@ -47,3 +47,49 @@ def test_rollout_buffer_columns_are_consistent():
         assert bool((buf.final_rewards[~ends] == 0).all())
     assert env.counters()["illegal"] == 0
     env.close()
+
+
+def test_native_rollout_call_equals_the_stepwise_loop_and_the_separate_episode_end_kernel():
+    """skyjo_vec_model_rollout (T iterations behind one call, two launches each) against the same loop made one launch at a
+    time from Python, and the step kernel's episode-end columns against skyjo_vec_episode_ends run on the stored records:
+    every column bit for bit.  Two engines seeded alike play the two forms."""
+    import ctypes as C
+
+    import torch
+
+    from skyjo_rl_amd import SkyjoVecEnv, _lib
+    from skyjo_rl_amd.action_mask_model import ActionMaskModel, FusedNet
+    from skyjo_rl_amd.rollout import RolloutBuffer, collect, collect_stepwise
+
+    torch.manual_seed(4)
+    B, N, T = 3000, 4, 150
+    model = ActionMaskModel(obs_dim=31).cuda()
+    pol, val = FusedNet(model.policy), FusedNet(model.value)
+    cols = []
+    for form in (collect, collect_stepwise):
+        env = SkyjoVecEnv(B, num_players=N)
+        env.seed(None, 33)
+        buf = RolloutBuffer(env, T)
+        for rnd in range(2):
+            form(env, pol, val, buf, seed=8, first_ticket=rnd * T, first_records=None if rnd == 0 else buf.records[T].clone())
+        cols.append([x.clone() for x in (buf.records, buf.actions, buf.logp, buf.values, buf.final_rewards, buf.episode_end)])
+        if form is collect:
+            L = _lib.load()
+            vp = lambda t: C.c_void_p(t.data_ptr())
+            fr, ee = torch.empty_like(buf.final_rewards[0]), torch.empty_like(buf.episode_end[0])
+            hits = 0
+            for t in range(T - 1):  # (the rewards of an ended game stay in place until the next step re-deals it)
+                if not bool(buf.episode_end[t].any()):
+                    continue
+                # re-derive from the records of step t; the engine's reward array still holds step T's state, so only the
+                # flags can be compared for earlier steps
+                _lib.check(L.skyjo_vec_episode_ends(env._h, vp(buf.records[t + 1]), vp(fr), vp(ee), env._stream()))
+                assert torch.equal(ee, buf.episode_end[t])
+                hits += 1
+            assert hits > 0
+            _lib.check(L.skyjo_vec_episode_ends(env._h, vp(buf.records[T]), vp(fr), vp(ee), env._stream()))
+            assert torch.equal(ee, buf.episode_end[T - 1]) and torch.equal(fr, buf.final_rewards[T - 1])
+        assert env.counters()["illegal"] == 0 and int(buf.episode_end.sum()) > 0
+        env.close()
+    for a, b in zip(*cols):
+        assert torch.equal(a, b)

@@ -2,6 +2,7 @@
 r*32768 ...), the product's statistics gather in two processes, whole-engine snapshot / restore, and the per-handle
 device guard of the C ABI."""
 import os
+import socket
 import subprocess
 import sys
 import threading
@@ -83,8 +84,11 @@ def test_two_rank_gather_of_product_engines_equals_single_process():
 
     script = _WORKER.format(root=ROOT)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as sock:  # a free port: suites may run side by side
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                          "127.0.0.1", "--master-port", "29731", _write_tmp(script)], env=env, capture_output=True, text=True,
+                          "127.0.0.1", "--master-port", str(port), _write_tmp(script)], env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
@@ -204,10 +208,34 @@ def test_step_kernel_gives_up_loudly_when_the_dealing_kernel_never_arrives():
     eng.rollout(360, policy_seed=1)              # three dealing cycles: the banks run dry while the deals sleep
     with pytest.raises(SkyjoNativeError, match="gave up waiting for the dealing kernel"):
         eng.counters()
+    # not only the counters - every synchronising call reports the voided run, and a snapshot of it is refused
+    for call in (eng.check_error, eng.observe_host, lambda: eng.step_host(np.full(128, 24, dtype=np.int32)), eng.rewards_host,
+                 lambda: eng.get_state(0), eng.snapshot):
+        with pytest.raises(SkyjoNativeError, match="gave up waiting for the dealing kernel"):
+            call()
     eng.set_debug_option(4, 0)
     eng.set_debug_option(3, 22)
     eng.seed(None, 2)                            # a new seeding clears the error
     eng.rollout(100, policy_seed=1)
     c = eng.counters()
     assert c["steps"] > 0 and c["episodes"] > 0
+    eng.check_error()
     eng.close()
+
+
+def test_snapshot_of_a_destroyed_handle_is_refused_by_its_successor():
+    """a snapshot remembers the handle's generation and its array table, not just its address."""
+    from skyjo_rl_amd import SkyjoNativeError
+
+    a = _engine(256, **CFG)
+    a.seed(None, 1)
+    snap = a.snapshot()
+    a.restore(snap)  # its own handle: fine
+    a.close()
+    for n in (256, 320):  # (the allocator likes to hand the same address to the next handle)
+        b = _engine(n, **dict(CFG, num_players=3 if n == 256 else 4))
+        b.seed(None, 1)
+        with pytest.raises(SkyjoNativeError, match="another handle|does not fit"):
+            b.restore(snap)
+        b.close()
+    snap.close()
