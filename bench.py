@@ -1,35 +1,48 @@
 #!/usr/bin/env python3
 """bench.py - env-steps/sec of the vectorised SkyJo hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3|4] [--blocks R] [--no-other-configs]
 
 A bench "step" is ONE FUSED LAUNCH of the hot path over the whole batch: `iterations_per_step` (88)
 lockstep iterations - in each of them every live game applies one action chosen by the on-device
 random admissible policy (state transition + observation / action-mask build, the 64-byte record
 with the applied action written to HBM) and finished games take their next deal - plus the dealing
-run (k_scan + k_deal) that the engine starts once per 88 iterations.  So `--steps 20 --warmup 5` are
-1 760 timed lockstep iterations after 440 untimed ones (about 16 episodes per game inside the timed
-region); the defaults are 250 / 25 launches.  Before the warm-up the freshly seeded games are run for 100 launches
-(set-up: seeded together they end their first episodes together).  The workload is BASELINE.json configs[2]: 65 536
-parallel 3-player games per GPU, DEFAULT_CONFIG (indirect observation, D = 31), game g seeded
-base + g, numpy-legacy MT19937 deals (bit-identical to the reference).  `value` = env-steps (applied
-actions, counted on device) of all ranks / max-over-ranks wall time, inputs resident in HBM.  One
-JSON line on stdout (rank 0).
+run (k_deal) that the engine starts once per 88 iterations.  So `--steps 20 --warmup 5` are 1 760
+timed lockstep iterations after 440 untimed ones (about 16 episodes per game inside a timed block).
+Before the warm-up the freshly seeded games are run for 100 launches (set-up: seeded together they
+end their first episodes together).
+
+Workload (`--config 3`, the default): BASELINE.json configs[2], 65 536 parallel 3-player games per GPU
+(weak scaling under --gpus N), DEFAULT_CONFIG (indirect observation, D = 31), game g seeded base + g,
+numpy-legacy MT19937 deals (bit-identical to the reference).  `--config 4`: BASELINE.json configs[3],
+32 768 games per GPU - 262 144 in total at --gpus 8 (the shard a rank runs at N < 8 is the same size).
+
+Timing: W untimed steps, then `--blocks` (5) timed blocks of EXACTLY K steps each, every block bracketed
+by a barrier + torch.cuda.synchronize() on both sides and taken as the MAX over ranks.  `value` /
+`ms_per_step` are the MEDIAN block (env-steps counted on device over all ranks / that block's time);
+`blocks` lists every block with min / max.  Inputs are resident in HBM.  One JSON line on stdout (rank 0).
 
 `--gpus N` (N > 1) without a torchrun environment starts the N ranks itself: a fresh
-`python -m torch.distributed.run` child, started before this process touches the GPU.
+`python -m torch.distributed.run` child, started before this process touches the GPU.  With more ranks
+than GPUs the run is refused unless SKYJO_BENCH_SHARED_GPU=1 (rehearsal: ranks share cards, gloo carries
+the statistics record).
 
 Extra objects on the same line:
   roofline       dominant kernel (k_step, fused rollout) timed with HIP events on its launch stream
-  roofline_path  the whole path (k_step + k_scan + k_deal [+ k_publish] per dealing cycle): kernel-time sum
-                 from the same events, and the wall time of the timed region
+  roofline_path  the whole path (k_step + k_deal per dealing cycle): kernel-time sum from the same events,
+                 and the wall time of the timed region
   episode_stats  what the ranks all-gather (RCCL): per-seat reward / score statistics
-  cpu_baseline   the CPU oracle (oracle/, a port of the reference's algorithm) timed on host cores
+  other_configs  (N = 1) short blocks of the other BASELINE.json configurations in the same run: cfg2 (4 096 x 2),
+                 the cfg4 shard (32 768 x 3, game_id0 = 3 * 32 768), cfg5 (65 536 x 4, the action-mask model's policy +
+                 value net in the loop, float32-grade and bf16), the counter-based RNG mode, the direct observation
+  cpu_baseline   the CPU oracle (oracle/, a port of the reference's algorithm) timed on host cores, with
+                 speedup_vs_cpu_port and speedup_vs_reference_constant beside it
 """
 import argparse
 import json
 import os
 import socket
+import statistics
 import subprocess
 import sys
 import time
@@ -38,10 +51,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (the guide's figure without sparsity)
 CHUNK = int(os.environ.get("SKYJO_BENCH_CHUNK", "0"))  # lockstep iterations per kernel launch; 0 = the engine's dealing interval
 SETTLE = int(os.environ.get("SKYJO_BENCH_SETTLE", "100"))  # launches between seeding and the warm-up (see main)
-                                                        # (88 for three and more players, <= kMaxRolloutChunk in skyjo_capi.hip)
+# the reference's own Python loop (core loop + policy_ra, N = 3, indirect observation), measured in the
+# build container (8-core Xeon 2.1 GHz); the reference cannot travel to the GPU box, so these are constants
+REFERENCE_STEPS_PER_S_1_CORE = 8.3e3
+REFERENCE_STEPS_PER_S_8_CORES = 52.8e3
+TRAFFIC_PROFILE = os.path.join("profiles", "r3_hbm_traffic.json")  # rocprofv3 PMC passes of this very launch shape (tools/refresh_profiles.sh)
 
 
 def algorithmic_bytes_per_launch(B, N, D, iters, records=True):
@@ -105,15 +123,133 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+ENV_CFG = dict(score_penalty=2.0, mean_reward=1.0, reward_refunded=0.001, auto_reset=True)
+
+
+def time_rollout(eng, chunk, launches, rec, sync):
+    """`launches` fused launches of `chunk` lockstep iterations; returns (seconds, env-steps applied, counters)."""
+    sync()
+    eng.reset_counters()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        eng.rollout(chunk, policy_seed=1, records=rec)
+    sync()
+    dt = time.perf_counter() - t0
+    return dt, eng.counters()
+
+
+def side_rollout_config(name, B, N, steps, warmup, device, rng_mode, indirect=True, game_id0=0, settle=40):
+    """One of the other BASELINE configurations as a short block in the same process: value, time per lockstep iteration, the
+    dominant kernel's launch time (HIP events) and its roofline fraction (SURVEY 8d bytes of that shape)."""
+    import torch
+    from skyjo_rl_amd import SkyjoVecEnv
+
+    eng = SkyjoVecEnv(B, num_players=N, observe_other_player_indirect=indirect, device=device, rng_mode=rng_mode, game_id0=game_id0,
+                      **ENV_CFG)
+    eng.seed(None, 0)
+    chunk = eng.deal_interval()
+    rec = eng.new_records(chunk)
+    sync = torch.cuda.synchronize
+    for _ in range(settle + warmup):
+        eng.rollout(chunk, policy_seed=1, records=rec)
+    chunk2 = eng.deal_interval()  # (the interval adapts itself while the banks settle)
+    if chunk2 != chunk:
+        chunk = chunk2
+        rec = eng.new_records(chunk)
+    dt, c = time_rollout(eng, chunk, steps, rec, sync)
+    eng.profile(1)
+    for _ in range(16):
+        eng.rollout(chunk, policy_seed=1, records=rec)
+    prof = eng.profile(0)
+    k_ms = prof["step_ms"] / max(prof["step_launches"], 1)
+    alg = algorithmic_bytes_per_launch(B, N, eng.obs_dim, chunk)
+    out = {"workload": f"{B} x {N}-player games, {'indirect' if indirect else 'direct'} observation D={eng.obs_dim}, "
+                       f"{'mt19937' if rng_mode == 0 else 'philox'} deals" + (f", game_id0={game_id0}" if game_id0 else ""),
+           "value": c["steps"] / dt, "unit": "env-steps/s", "ms_per_iteration": 1e3 * dt / (steps * chunk),
+           "iterations_per_launch": chunk, "timed_launches": steps, "dominant_kernel": "k_step",
+           "dominant_kernel_ms": k_ms, "deal_kernel_ms": prof["deal_ms"] / max(prof["deal_launches"], 1),
+           "roofline_frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
+           "dealing": "beside k_step" if eng.overlap() else "in line", "waits": int(c["waits"]),
+           "mean_episode_len": c["sum_len"] / max(c["episodes"], 1)}
+    eng.close()
+    return out
+
+
+def side_model_config(precision, B, N, T, rounds, device):
+    """BASELINE configs[4]: 65 536 four-player games, every action drawn by the action-mask model (policy + value branch in one
+    launch, random weights), collected by skyjo_vec_model_rollout - two launches per lockstep iteration."""
+    import torch
+    from skyjo_rl_amd import SkyjoVecEnv
+    from skyjo_rl_amd.action_mask_model import ActionMaskModel, FusedNet
+    from skyjo_rl_amd.rollout import RolloutBuffer, collect
+
+    torch.manual_seed(0)
+    env = SkyjoVecEnv(B, num_players=N, device=device, **ENV_CFG)
+    env.seed(None, 3)
+    model = ActionMaskModel(obs_dim=env.obs_dim).cuda()
+    pol, val = FusedNet(model.policy, device=device, precision=precision), FusedNet(model.value, device=device, precision=precision)
+    buf = RolloutBuffer(env, T)
+    collect(env, pol, val, buf, seed=9, first_ticket=0)  # warm-up (incl. the first episodes' common end)
+    collect(env, pol, val, buf, seed=9, first_ticket=T, first_records=buf.records[T].clone())
+    torch.cuda.synchronize()
+    env.reset_counters()
+    t0 = time.perf_counter()
+    for r in range(rounds):
+        collect(env, pol, val, buf, seed=9, first_ticket=(2 + r) * T, first_records=buf.records[T].clone())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c = env.counters()
+    env.profile(1)
+    collect(env, pol, val, buf, seed=9, first_ticket=(2 + rounds) * T, first_records=buf.records[T].clone())
+    prof = env.profile(0)
+    mlp_ms = prof["k_mlp_ms"] / max(prof["k_mlp_launches"], 1)
+    flops = 2.0 * B * 2 * (32 * 256 + 256 * 256 + 256 * 32)  # policy + value net, the model's own (float32) multiply-adds
+    out = {"workload": f"{B} x {N}-player games, action-mask model (policy + value net, 256-256 tanh, random weights) picks every action; "
+                       f"skyjo_vec_model_rollout: 2 launches per lockstep iteration, rollout columns written",
+           "precision": precision, "value": c["steps"] / dt, "unit": "env-steps/s", "ms_per_iteration": 1e3 * dt / (rounds * T),
+           "timed_iterations": rounds * T, "dominant_kernel": "k_mlp_forward_split" if precision == "fp32" else "k_mlp_forward",
+           "dominant_kernel_ms": mlp_ms, "step_kernel_ms": prof["step_ms"] / max(prof["step_launches"], 1),
+           "roofline_bound": "mfma", "roofline_achieved_tflops": flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else None,
+           "roofline_frac": flops / (mlp_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS if mlp_ms > 0 else None,
+           "mfma_issue_frac": (3.0 if precision == "fp32" else 1.0) * flops / (mlp_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS if mlp_ms > 0 else None,
+           "illegal": int(c["illegal"]), "mean_episode_len": c["sum_len"] / max(c["episodes"], 1)}
+    pol.close(), val.close(), env.close()
+    return out
+
+
+def other_configs(device, steps, warmup):
+    out = {}
+    t0 = time.perf_counter()
+    from skyjo_rl_amd import RNG_MT19937, RNG_PHILOX
+    for name, fn in (
+            ("cfg2_4096x2", lambda: side_rollout_config("cfg2", 4096, 2, 4 * steps, warmup, device, RNG_MT19937)),
+            ("cfg4_shard_32768x3", lambda: side_rollout_config("cfg4", 32768, 3, 2 * steps, warmup, device, RNG_MT19937, game_id0=3 * 32768)),
+            ("cfg5_65536x4_model_fp32", lambda: side_model_config("fp32", 65536, 4, 64, 4, device)),
+            ("cfg5_65536x4_model_bf16", lambda: side_model_config("bf16", 65536, 4, 64, 4, device)),
+            ("philox_65536x3", lambda: side_rollout_config("philox", 65536, 3, steps, warmup, device, RNG_PHILOX)),
+            ("direct_obs_65536x3", lambda: side_rollout_config("direct", 65536, 3, steps, warmup, device, RNG_MT19937, indirect=False))):
+        try:
+            out[name] = fn()
+        except Exception as e:  # a side configuration must not take the headline line down with it
+            out[name] = {"error": repr(e)}
+    out["seconds"] = time.perf_counter() - t0
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=250, help="timed fused launches of 88 lockstep iterations each")
-    ap.add_argument("--warmup", type=int, default=25, help="untimed launches before them")
-    ap.add_argument("--num-envs", type=int, default=65536, help="games per GPU")
+    ap.add_argument("--steps", type=int, default=100, help="fused launches of 88 lockstep iterations per timed block")
+    ap.add_argument("--warmup", type=int, default=25, help="untimed launches before the first block")
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps launches each (value = the median block)")
+    ap.add_argument("--config", type=int, choices=[3, 4], default=3,
+                    help="3: 65 536 games per GPU (BASELINE configs[2], weak scaling); 4: 32 768 per GPU (configs[3]: 262 144 at --gpus 8)")
+    ap.add_argument("--num-envs", type=int, default=None, help="games per GPU (overrides --config)")
     ap.add_argument("--num-players", type=int, default=3)
     ap.add_argument("--rng", choices=["mt19937", "philox"], default="mt19937")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short blocks of the other BASELINE configurations")
     ap.add_argument("--no-records", action="store_true", help="do not write records (not the headline)")
     ap.add_argument("--actions-array", action="store_true", help="also write the int32 action array (the action is byte D of every record anyway)")
     ap.add_argument("--direct-obs", action="store_true", help="observe_other_player_indirect=False: D = 19 + 12 N (not the headline)")
@@ -134,21 +270,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = torch.cuda.device_count()
     assert ndev > 0, "bench.py needs a GPU"
-    shared_gpu = world > ndev  # rehearsal on a box with fewer GPUs than ranks: ranks share cards, gloo carries the record
+    shared_gpu = world > ndev
+    if shared_gpu and os.environ.get("SKYJO_BENCH_SHARED_GPU") != "1":
+        # one rank per GPU over RCCL is the measured configuration; silently sharing cards would report a scaling number that is none
+        sys.stderr.write(f"bench.py: --gpus {world} but only {ndev} GPU(s) visible - refusing to let ranks share a card.  "
+                         f"(SKYJO_BENCH_SHARED_GPU=1 allows it as a REHEARSAL of the launch path: gloo carries the statistics record.)\n")
+        sys.exit(3)
     device = local_rank % ndev
     if world > 1:
         if shared_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))  # RCCL
     torch.cuda.set_device(device)
     dev = torch.device("cuda", device)
 
-    B, N = args.num_envs, args.num_players
+    B = args.num_envs if args.num_envs else (65536 if args.config == 3 else 32768)
+    N = args.num_players
     # shards by global game id (rank r owns games r*B .. (r+1)*B - 1): results do not depend on the GPU count
-    eng = make_sharded_env(world * B, rank, world, num_players=N, score_penalty=2.0, observe_other_player_indirect=not args.direct_obs,
-                           mean_reward=1.0, reward_refunded=0.001, device=device,
-                           rng_mode=RNG_MT19937 if args.rng == "mt19937" else RNG_PHILOX, auto_reset=True)
+    eng = make_sharded_env(world * B, rank, world, num_players=N, observe_other_player_indirect=not args.direct_obs, device=device,
+                           rng_mode=RNG_MT19937 if args.rng == "mt19937" else RNG_PHILOX, **ENV_CFG)
     assert eng.num_envs == B and eng.game_id0 == rank * B
     eng.seed(None, 0)
     global CHUNK
@@ -174,32 +315,37 @@ def main():
     # 2.91 / 2.92 / 3.01 / 3.05 / 3.04 x 10^10 steps/s), so the games are run for SETTLE launches before the warm-up starts.
     run(SETTLE)
     run(args.warmup)
-    barrier()
-    c0 = eng.counters()
-    eng.reset_counters()
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    c1 = eng.counters()
-
-    # the one collective of the path: per-rank episode statistics (counts + per-seat reward / score sums), all-gathered
-    # over RCCL (device tensors; gloo when ranks share a card)
-    c1["wall"] = dt
-    per_rank, tot = gather_stats(c1, N, device=dev)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_max = float(t.item())
-    else:
-        t_max = dt
-    steps_total = float(tot["steps"])
+    blocks = []
+    for b in range(max(args.blocks, 1)):
+        barrier()
+        eng.reset_counters()
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        c1 = eng.counters()
+        # every rank must have been in steady state: games ended and were re-dealt inside the timed region, nobody dealt in place
+        assert c1["episodes"] > 0 and c1["resets"] > 0, "no episode ended inside the timed region: --steps too small to mean anything"
+        assert c1["waits"] == 0 or os.environ.get("SKYJO_BENCH_ALLOW_WAITS"), f"{c1['waits']} deals were made on the in-kernel slow path (bank ran dry)"
+        assert c1["iters"] == args.steps * CHUNK
+        # the one collective of the path: per-rank episode statistics (counts + per-seat reward / score sums), all-gathered
+        # over RCCL (device tensors; gloo when ranks share a card)
+        c1["wall"] = dt
+        per_rank, tot = gather_stats(c1, N, device=dev)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_max = float(t.item())
+        else:
+            t_max = dt
+        blocks.append({"t_max": t_max, "steps": float(tot["steps"]), "value": float(tot["steps"]) / t_max, "tot": tot, "per_rank": per_rank,
+                       "c1": c1})
+    order = sorted(range(len(blocks)), key=lambda i: blocks[i]["value"])
+    med = blocks[order[len(order) // 2]]
+    t_max, tot, per_rank, c1 = med["t_max"], med["tot"], med["per_rank"], med["c1"]
+    steps_total = med["steps"]
     episodes = float(tot["episodes"])
-    # every rank must have been in steady state: games ended and were re-dealt inside the timed region, nobody dealt in place
-    assert c1["episodes"] > 0 and c1["resets"] > 0, "no episode ended inside the timed region: --steps too small to mean anything"
-    assert c1["waits"] == 0 or os.environ.get("SKYJO_BENCH_ALLOW_WAITS"), f"{c1['waits']} deals were made on the in-kernel slow path (bank ran dry)"
-    assert c1["iters"] == args.steps * CHUNK
 
     # roofline leg: the same launches again, every kernel carrying a HIP event pair that receives its begin / end
     # timestamps on its launch stream (comparable with rocprofv3's kernel trace, profiles/)
@@ -210,10 +356,13 @@ def main():
     avg_ms = prof["step_ms"] / max(full, 1)
     alg = algorithmic_bytes_per_launch(B, N, D, CHUNK, records=record) + (4 * B * CHUNK if act is not None else 0)
     achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")
-    if os.path.exists(tpath) and B == 65536 and N == 3 and record and act is None and CHUNK == 88:  # (the PMC passes ran this very launch shape)
+    traffic, traffic_source = None, None
+    tpath = os.path.join(ROOT, TRAFFIC_PROFILE)
+    if os.path.exists(tpath) and B == 65536 and N == 3 and record and act is None and CHUNK == 88 and not args.direct_obs and args.rng == "mt19937":
+        # NOT measured in this run: PMC counters need rocprofv3 around the process.  The figure is the committed profile of this
+        # very launch shape; `traffic_source` says so.
         traffic = json.load(open(tpath)).get("k_step_bytes_per_launch")
+        traffic_source = f"{TRAFFIC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch shape, collected by tools/refresh_profiles.sh; not measured in this run)"
     kernel_ms = {k: prof[k + "_ms"] / 32.0 for k in ("k_step", "k_scan", "k_deal", "k_publish")}  # per bench step (= per dealing cycle)
     path_ms = sum(kernel_ms.values())
     wall_ms = 1e3 * t_max / args.steps
@@ -223,9 +372,14 @@ def main():
     deal_alg = deals_per_step * ((24 * N + 150 + 16) + (12.0 * rng_outputs_per_deal(N) if args.rng == "mt19937" else 0.0))
 
     if rank == 0:
+        vals = [b["value"] for b in blocks]
+        if args.num_envs is None and args.config == 4:
+            scaling_note = f"BASELINE configs[3]: 32 768 games per GPU ({world * B} in total; 262 144 at --gpus 8)"
+        else:
+            scaling_note = f"weak: {B} games per GPU ({world * B} in total)"
         out = {
             "metric": "env-steps/sec (whole node) at 65 536 parallel 3-player games",
-            "value": steps_total / t_max,
+            "value": med["value"],
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -240,14 +394,18 @@ def main():
                                    f"{'direct' if args.direct_obs else 'DEFAULT_CONFIG (indirect'} obs D={D}{'' if args.direct_obs else ')'}, auto-reset, "
                                    f"record (obs + mask + applied action) written every step; one bench step = one fused launch of {CHUNK} lockstep iterations + its dealing run"
                                    if record else f"{B} x {N}-player games per GPU, no records",
+                       "baseline_config": args.config if args.num_envs is None else None,
                        "games_per_gpu": B, "num_players": N, "rng_mode": args.rng,
-                       "iterations_per_step": CHUNK, "timed_iterations": args.steps * CHUNK, "warmup_iterations": args.warmup * CHUNK,
+                       "iterations_per_step": CHUNK, "timed_iterations_per_block": args.steps * CHUNK, "warmup_iterations": args.warmup * CHUNK,
                        "settle_launches_before_warmup": SETTLE,
                        "dealing": ("beside k_step (own stream; k_scan + k_publish)" if os.environ.get("SKYJO_PIPELINED") == "0" else
                                    "beside k_step (own stream; planned and published by k_step itself)") if eng.overlap() else
                                   ("in line (k_scan + k_deal)" if os.environ.get("SKYJO_FUSED_SCAN") == "0" else "in line (k_deal scans the banks itself)"),
                        "shared_gpu_rehearsal": shared_gpu,
-                       "parallelism": f"games sharded over {world} GPU(s) by global game id, no data-path collective; one all-gather of the statistics record"},
+                       "parallelism": f"{scaling_note}; games sharded over {world} GPU(s) by global game id, no data-path collective; "
+                                      f"one all-gather of the statistics record ({'gloo: ranks share a card' if shared_gpu else 'RCCL' if world > 1 else 'single rank'})"},
+            "blocks": {"n": len(blocks), "steps_per_block": args.steps, "values": vals, "median": med["value"], "min": min(vals), "max": max(vals),
+                       "rel_spread": (max(vals) - min(vals)) / med["value"], "ms_per_step": [1e3 * b["t_max"] / args.steps for b in blocks]},
             "ms_per_iteration": wall_ms / CHUNK,
             "mean_episode_len": float(tot["mean_episode_len"]),
             "episodes": episodes,
@@ -258,9 +416,9 @@ def main():
                               "mean_score_per_seat": [float(x) for x in tot["mean_score"]],
                               "refunded_per_episode": float(tot["sum_refunded"].sum() / max(episodes, 1.0))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step<indirect,policy,3>" if N == 3 and record else "k_step", "avg_launch_ms": avg_ms, "launches_timed": full,
-                         "algorithmic_bytes_per_launch": alg,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": f"k_step<{'indirect' if not args.direct_obs else 'direct'},policy,{N if N in (2, 3, 4) else 0}>", "avg_launch_ms": avg_ms,
+                         "launches_timed": full, "algorithmic_bytes_per_launch": alg,
                          "deal_kernel_avg_ms": prof["deal_ms"] / max(prof["deal_launches"], 1)},
             "roofline_path": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                               "kernel_ms_per_step": kernel_ms, "kernel_ms_sum": path_ms,
@@ -280,10 +438,20 @@ def main():
                                       "has to move (not part of SURVEY 8d's per-step figure); with the dealing kernel on its own stream the kernel times "
                                       "overlap and only the wall figures are path times"},
         }
+    eng.close()
+    if rank == 0:
+        if world == 1 and not args.no_other_configs:
+            out["other_configs"] = other_configs(device, max(args.steps, 10), max(args.warmup, 5))
+        out["speedup_vs_reference_constant"] = {
+            "vs_1_core": med["value"] / REFERENCE_STEPS_PER_S_1_CORE, "vs_8_cores": med["value"] / REFERENCE_STEPS_PER_S_8_CORES,
+            "reference_steps_per_s": {"1_core": REFERENCE_STEPS_PER_S_1_CORE, "8_cores": REFERENCE_STEPS_PER_S_8_CORES},
+            "source": "BASELINE.md section 2: the reference's Python core loop + policy_ra (N = 3, indirect observation), measured in the build "
+                      "container (8-core Xeon 2.1 GHz) - the reference cannot run on the GPU box"}
         if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: a reported baseline, not part of the scaling runs)
             out["cpu_baseline"] = cpu_baseline(N)
+            out["speedup_vs_cpu_port"] = {"vs_all_host_threads": med["value"] / out["cpu_baseline"]["value"],
+                                          "vs_1_thread": med["value"] / out["cpu_baseline"]["value_1_thread"]}
         print(json.dumps(out), flush=True)
-    eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -194,11 +194,21 @@ int skyjo_vec_set_state(skyjo_vec *h, int32_t game, const skyjo_game_state *in_h
 /* np.random.seed(value) on one game's legacy stream without dealing (fixture injection) */
 int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream);
 
+/* The reference draws its deals and mid-game reshuffles from numpy's process-global legacy stream (skyjo.py:81,94,101,135),
+ * the same one policy_ra(obs, mask) without a generator draws from (random_admissible_policy.py:22-23).  For a handle in
+ * MT19937 mode with SKYJO_OPT_NO_BANK these two calls move that stream in and out of one game in numpy's own terms -
+ * np.random.get_state(): key uint32[624], pos 0..624 - so a single-game view can hand the caller's stream to the device
+ * before a deal or a reshuffle and hand it back afterwards (skyjo_rl_amd/game.py: SkyjoGame(global_rng=True)).
+ * get_state returns the block completed the way numpy keeps it (the engine regenerates the state lazily).  Both synchronise. */
+int skyjo_vec_rng_set_state(skyjo_vec *h, int32_t game, const uint32_t *key_host, int32_t pos, void *stream);
+int skyjo_vec_rng_get_state(skyjo_vec *h, int32_t game, uint32_t *key_out_host, int32_t *pos_out_host, void *stream);
+
 /* Kernel timing with HIP events on the launch stream: while enabled, every kernel of the path is launched with a
  * (start, stop) event pair that receives the kernel's own begin and end timestamps.  Returns and clears what was
  * collected since the last call - sum of milliseconds and launch count per kernel: [0] k_step, [1] k_scan, [2] k_deal,
- * [3] k_publish - then switches collection on (1) or off (0).  Synchronises the device. */
-#define SKYJO_PROF_KERNELS 4
+ * [3] k_publish, [4] the policy / value net launches of skyjo_vec_model_rollout - then switches collection on (1) or off (0).
+ * Synchronises the device. */
+#define SKYJO_PROF_KERNELS 5
 int skyjo_vec_profile(skyjo_vec *h, int enable, double ms_out[SKYJO_PROF_KERNELS], int64_t launches_out[SKYJO_PROF_KERNELS]);
 
 /* Snapshot / restore of the WHOLE engine (the reference has no such feature): every live game, every bank
@@ -233,6 +243,10 @@ int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
  * skyjo_vec_get_counters reports; SKYJO_OPT_DEBUG_DEAL_DELAY - every dealing wavefront sleeps value x 8128 cycles first. */
 #define SKYJO_OPT_DEBUG_SPIN_LOG2 3
 #define SKYJO_OPT_DEBUG_DEAL_DELAY 4
+/* SKYJO_OPT_NO_BANK (set before skyjo_vec_seed): 1 = no episodes are dealt ahead - every reset deals in place from the
+ * stream's current position, exactly when the reference would (skyjo.py:52-74).  Slow for batches; it is what lets ONE
+ * game share the process-global numpy stream with its caller (skyjo_vec_rng_set_state / _get_state below). */
+#define SKYJO_OPT_NO_BANK 5
 int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value);
 int skyjo_vec_get_option(const skyjo_vec *h, int option, int64_t *value_out);
 
@@ -315,7 +329,10 @@ typedef struct skyjo_vec_rollout_buffers {
 int skyjo_vec_model_rollout(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, int32_t T, uint64_t seed,
                             uint64_t first_ticket, int32_t no_masking, const skyjo_vec_rollout_buffers *buffers, void *stream);
 
-/* host-pointer conveniences for small batches (single-game AEC view): synchronous */
+/* host-pointer conveniences for small batches (single-game AEC view): synchronous.  Up to 4096 games they go through
+ * host-mapped memory (one launch + one synchronisation per call, no copies), and step_host / reset_host bring every game's
+ * state and rewards back with the records: skyjo_vec_get_state and skyjo_vec_get_rewards_host right after them cost no
+ * device traffic. */
 int skyjo_vec_step_host(skyjo_vec *h, const int32_t *actions_host, void *records_out_host);
 int skyjo_vec_observe_host(skyjo_vec *h, const int32_t *players_host, void *records_out_host);
 int skyjo_vec_reset_host(skyjo_vec *h, const uint8_t *mask_host, void *records_out_host);

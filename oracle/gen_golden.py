@@ -22,6 +22,12 @@ inputs -> outputs of the hot path:
                    including the TerminateIllegalWrapper flow
   render.npz       the text the reference's render utils print (skyjo.py:508-602) for fresh,
                    mid-game, collapsed-column, empty-discard and terminated states
+  global_*.npz     the reference's OWN caller loops on the process-global numpy stream: np.random.seed(s),
+                   then sample_run (rlskyjo/game/sample_game.py:5-28) / simple_episode
+                   (rlskyjo/environment/vanilla_env_example.py:6-41) with policy_ra(obs, mask) and NO generator
+                   (random_admissible_policy.py:22-23): deals, mid-game reshuffles and the policy's draws all
+                   come out of the one stream, in the order the loops make them; the stream's state is
+                   recorded at every episode end
 
 The fixtures are data (inputs and expected outputs) - no reference source text is stored.
 """
@@ -428,6 +434,90 @@ def gen_env(cfg, seed, name, illegal_at=None, illegal_action=None, episodes=2):
     return len(rows["agent"])
 
 
+def _np_state():
+    st = np.random.get_state(legacy=True)
+    return np.asarray(st[1], dtype=np.uint32).copy(), int(st[2])
+
+
+def gen_global_core(N, np_seed, indirect, episodes, name, penalty=2.0):
+    """sample_run (rlskyjo/game/sample_game.py:5-28) on the process-global stream: np.random.seed(np_seed); SkyjoGame(...)
+    deals in its constructor (skyjo.py:49); every game starts with reset(); policy_ra(obs, mask) draws from np.random."""
+    np.random.seed(np_seed)
+    g = SkyjoGame(num_players=N, score_penalty=penalty, observe_other_player_indirect=indirect)
+    rows = {k: [] for k in ("player", "phase", "action", "obs", "mask", "over", "n_draw")}
+    ep_start, keys, poss, finals, deals = [0], [], [], [], []
+    for ep in range(episodes):
+        g.reset()
+        deals.append(np.array(g.players_cards, dtype=np.int8).copy())
+        while not g.is_terminated:
+            pid, phase = g.expected_action
+            obs, mask = g.collect_observation(pid)
+            a = int(policy_ra(obs, mask))
+            rows["player"].append(pid), rows["phase"].append(0 if phase == "draw" else 1), rows["action"].append(a)
+            rows["obs"].append(np.asarray(obs, dtype=np.int8)), rows["mask"].append(np.asarray(mask, dtype=np.int8))
+            rows["n_draw"].append(len(g.drawpile))
+            rows["over"].append(int(bool(g.act(pid, a))))
+        ep_start.append(len(rows["action"]))
+        k, p = _np_state()
+        keys.append(k), poss.append(p)
+        finals.append(np.asarray(g.game_metrics["final_score"], dtype=np.float64))
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), kind="global_core", num_players=N, np_seed=np_seed, indirect=int(indirect),
+        score_penalty=float(penalty), ep_start=np.asarray(ep_start, dtype=np.int32),
+        player=np.asarray(rows["player"], dtype=np.int32), phase=np.asarray(rows["phase"], dtype=np.int32),
+        action=np.asarray(rows["action"], dtype=np.int32), obs=np.asarray(rows["obs"], dtype=np.int8),
+        mask=np.asarray(rows["mask"], dtype=np.int8), over=np.asarray(rows["over"], dtype=np.int32),
+        n_draw=np.asarray(rows["n_draw"], dtype=np.int32), deal_cards=np.asarray(deals, dtype=np.int8),
+        final_score=np.asarray(finals, dtype=np.float64), end_key=np.asarray(keys, dtype=np.uint32),
+        end_pos=np.asarray(poss, dtype=np.int32))
+    return len(rows["action"])
+
+
+def gen_global_env(cfg, np_seed, name, episodes=2):
+    """simple_episode (rlskyjo/environment/vanilla_env_example.py:6-41) on the process-global stream, pettingzoo
+    stand-ins underneath ("wrapper semantics unpinned"): np.random.seed(np_seed); env(**cfg) (its SkyjoGame deals in
+    the constructor); reset(); agent_iter / last / step with policy_ra(obs, mask)."""
+    np.random.seed(np_seed)
+    e = skyjo_env.env(**cfg)
+    N = cfg["num_players"]
+    rows = {k: [] for k in ("agent", "done", "cum_reward", "action", "obs", "mask")}
+    ep_start, keys, poss = [0], [], []
+    for ep in range(episodes):
+        e.reset()
+        for agent in e.agent_iter(max_iter=300 * N):
+            obs, reward, done, info = e.last()
+            rows["agent"].append(int(agent.split("_")[-1])), rows["done"].append(int(done)), rows["cum_reward"].append(float(reward))
+            rows["obs"].append(np.asarray(obs["observations"], dtype=np.int8)), rows["mask"].append(np.asarray(obs["action_mask"], dtype=np.int8))
+            if not done:
+                a = int(policy_ra(obs["observations"], obs["action_mask"]))
+                rows["action"].append(a)
+                e.step(a)
+            else:
+                rows["action"].append(-1)
+                e.step(None)
+        ep_start.append(len(rows["agent"]))
+        k, p = _np_state()
+        keys.append(k), poss.append(p)
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), kind="global_env", wrapper_semantics="unpinned (pettingzoo stand-ins)",
+        num_players=N, np_seed=np_seed, indirect=int(cfg["observe_other_player_indirect"]),
+        score_penalty=float(cfg["score_penalty"]), mean_reward=float(cfg["mean_reward"]),
+        reward_refunded=float(cfg["reward_refunded"]), ep_start=np.asarray(ep_start, dtype=np.int32),
+        agent=np.asarray(rows["agent"], dtype=np.int32), done=np.asarray(rows["done"], dtype=np.int32),
+        cum_reward=np.asarray(rows["cum_reward"], dtype=np.float64), action=np.asarray(rows["action"], dtype=np.int32),
+        obs=np.asarray(rows["obs"], dtype=np.int8), mask=np.asarray(rows["mask"], dtype=np.int8),
+        end_key=np.asarray(keys, dtype=np.uint32), end_pos=np.asarray(poss, dtype=np.int32))
+    return len(rows["agent"])
+
+
+def gen_global():
+    n = gen_global_core(3, 7, True, 3, "global_core_N3_s7")
+    n += gen_global_core(2, 11, False, 3, "global_core_N2_dir_s11")
+    n += gen_global_core(12, 5, True, 1, "global_core_N12_s5")  # ~17 mid-game reshuffles between the policy's draws
+    n += gen_global_env(dict(skyjo_env.DEFAULT_CONFIG), 7, "global_env_default_s7")
+    return n
+
+
 def render_strings(g):
     """Everything the reference can print about one state (skyjo.py:508-562)."""
     N = g.num_players
@@ -509,6 +599,9 @@ def main():
     if "--render-only" in sys.argv:
         print("render", gen_render())
         return
+    if "--global-only" in sys.argv:
+        print("global", gen_global())
+        return
     gen_rng_kat()
     total = 0
     for N in (1, 2, 3, 4):
@@ -536,6 +629,7 @@ def main():
     print("env", gen_env(dict(skyjo_env.DEFAULT_CONFIG), 3, "env_illegal_draw_s3", illegal_at=4, illegal_action=3))
     print("env", gen_env(dict(skyjo_env.DEFAULT_CONFIG), 3, "env_illegal_place_s3", illegal_at=7, illegal_action=25))
     print("render", gen_render())
+    print("global", gen_global())
     sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes", sz)
 

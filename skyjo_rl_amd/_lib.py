@@ -15,7 +15,7 @@ ST_OK, ST_ILLEGAL, ST_NOOP_DONE, ST_RESET, ST_ERROR = 0, 1, 2, 3, 4
 RNG_MT19937, RNG_PHILOX = 0, 1
 MLP_BF16, MLP_FP32 = 0, 1  # SKYJO_MLP_*: precision of a packed policy / value net
 ACTION_SKIP = -1000  # SKYJO_ACTION_SKIP: leave this game as it is (skyjo_vec_step)
-PROF_KERNELS = ("k_step", "k_scan", "k_deal", "k_publish")
+PROF_KERNELS = ("k_step", "k_scan", "k_deal", "k_publish", "k_mlp")
 
 
 class SkyjoNativeError(RuntimeError):
@@ -51,6 +51,21 @@ class GameState(C.Structure):
                 ("reshuffles", C.c_uint32), ("num_refunded", C.c_int32 * MAX_PLAYERS),
                 ("num_placed", C.c_int32 * MAX_PLAYERS), ("final_score", C.c_double * MAX_PLAYERS),
                 ("rewards", C.c_double * MAX_PLAYERS)]
+
+
+# the same struct as a numpy record (aligned like the C compiler lays it out; tests/test_capi_symbols.py compares the sizes)
+import numpy as _np  # noqa: E402
+
+GAME_STATE_DTYPE = _np.dtype([
+    ("players_cards", _np.int8, (MAX_PLAYERS, 12)), ("players_masked", _np.int8, (MAX_PLAYERS, 12)),
+    ("drawpile", _np.int8, (150,)), ("discard_pile", _np.int8, (150,)), ("n_draw", _np.int16), ("n_disc", _np.int16),
+    ("hand_card", _np.int8), ("expected_player", _np.uint8), ("expected_phase", _np.uint8), ("is_terminated", _np.uint8),
+    ("done", _np.uint8), ("status", _np.uint8), ("episode_steps", _np.uint16), ("episode", _np.uint32),
+    ("reshuffles", _np.uint32), ("num_refunded", _np.int32, (MAX_PLAYERS,)), ("num_placed", _np.int32, (MAX_PLAYERS,)),
+    ("final_score", _np.float64, (MAX_PLAYERS,)), ("rewards", _np.float64, (MAX_PLAYERS,))], align=True)
+assert GAME_STATE_DTYPE.itemsize == C.sizeof(GameState), (GAME_STATE_DTYPE.itemsize, C.sizeof(GameState))
+for _f in ("n_draw", "hand_card", "episode_steps", "episode", "num_refunded", "final_score", "rewards"):
+    assert GAME_STATE_DTYPE.fields[_f][1] == getattr(GameState, _f).offset, _f
 
 
 class RolloutBuffers(C.Structure):
@@ -90,6 +105,8 @@ SIGNATURES = {
     "skyjo_vec_get_state": (C.c_int, [VP, I32, C.POINTER(GameState), VP]),
     "skyjo_vec_set_state": (C.c_int, [VP, I32, C.POINTER(GameState), VP]),
     "skyjo_vec_seed_raw": (C.c_int, [VP, I32, U32, VP]),
+    "skyjo_vec_rng_set_state": (C.c_int, [VP, I32, VP, I32, VP]),
+    "skyjo_vec_rng_get_state": (C.c_int, [VP, I32, VP, C.POINTER(I32), VP]),
     "skyjo_vec_profile": (C.c_int, [VP, C.c_int, C.POINTER(C.c_double), C.POINTER(I64)]),
     "skyjo_vec_snapshot_create": (C.c_int, [VP, C.POINTER(VP), VP]),
     "skyjo_vec_snapshot_restore": (C.c_int, [VP, VP, VP]),

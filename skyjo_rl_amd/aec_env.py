@@ -60,7 +60,10 @@ class SimpleSkyjoEnv:
     }
 
     def __init__(self, num_players=2, score_penalty: float = 2.0, observe_other_player_indirect: bool = False,
-                 mean_reward: float = 1.0, reward_refunded: float = 0.0, engine=None, device=0, wrapped=False):
+                 mean_reward: float = 1.0, reward_refunded: float = 0.0, engine=None, device=0, wrapped=False,
+                 global_rng=False):
+        """``global_rng=True``: deals and reshuffles draw from numpy's process-global stream like the reference's
+        (game.py has the contract), so ``np.random.seed(s)`` + ``policy_ra(obs, mask)`` loops replay the reference."""
         self.num_players = num_players
         self.mean_reward = mean_reward
         self.reward_refunded = reward_refunded
@@ -70,10 +73,11 @@ class SimpleSkyjoEnv:
             engine = SkyjoVecEnv(1, num_players=num_players, score_penalty=float(score_penalty),
                                  observe_other_player_indirect=observe_other_player_indirect,
                                  mean_reward=float(mean_reward), reward_refunded=float(reward_refunded),
-                                 device=device, auto_reset=False)
+                                 device=device, auto_reset=False, no_bank=bool(global_rng))
         self._engine = engine
         self.table = SkyjoGame(num_players, score_penalty=score_penalty,
-                               observe_other_player_indirect=observe_other_player_indirect, engine=engine)
+                               observe_other_player_indirect=observe_other_player_indirect, engine=engine,
+                               global_rng=global_rng)
         # wrapper behaviour of env() (skyjo_env.py:22-25) folded into this object when wrapped=True
         self._wrapped = wrapped
         self._has_reset = False

@@ -76,6 +76,7 @@ struct skyjo_vec {
   SkParams P{};
   size_t G = 0;           // tiles * 64
   size_t lds_bytes = 0, lds_tile = 0;
+  size_t lds_rollout = 0;  // the fused rollout kernels of 2 / 3 / 4 players keep their statistics in registers: smaller footprint
   bool seeded = false;
   int pending_iters = 0;  // lockstep iterations since the dealing kernel last ran
   int deal_every_iters = 64;  // set from deal_interval_default() in skyjo_vec_create
@@ -98,6 +99,18 @@ struct skyjo_vec {
   uint32_t deal_tag = 0;  // k_step launches between two k_deal launches inside skyjo_vec_rollout
   uint64_t iter = 0;        // rollout iterations (the policy's Philox counter)
   uint64_t iters_total = 0; // lockstep iterations of any kind since the counters were reset
+  // Small batches (single-game views): the *_host conveniences go through host-mapped memory - the kernel reads the actions
+  // from it and writes the records AND every game's packed state, rewards and scores to it (sk_export_raw), so a call is one
+  // launch + one stream synchronisation, and skyjo_vec_get_state / get_rewards_host afterwards are served from `hm_raw`
+  // (raw_valid) without touching the device.
+  bool fast_host = false, raw_valid = false;
+  uint8_t *hm_block = nullptr;  // one hipHostMalloc: actions | mask | records | raw
+  int32_t *hm_actions = nullptr;
+  uint8_t *hm_mask = nullptr, *hm_records = nullptr, *hm_raw = nullptr;
+  int32_t *hm_actions_d = nullptr;
+  uint8_t *hm_mask_d = nullptr, *hm_records_d = nullptr, *hm_raw_d = nullptr;
+  int raw_stride = 0;
+  bool no_bank = false;  // SKYJO_OPT_NO_BANK: no pre-dealt episodes, every deal is made in place from the stream's position
   // lazily allocated scratch for the *_host conveniences
   int32_t *d_actions = nullptr;
   uint8_t *d_records = nullptr;
@@ -113,7 +126,7 @@ struct skyjo_vec {
   int arena_mode = 0;  // 1: adding up, 2: carving
   // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
   bool profile = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[SKYJO_PROF_KERNELS];  // k_step, k_scan, k_deal, k_publish
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[SKYJO_PROF_KERNELS];  // k_step, k_scan, k_deal, k_publish, k_mlp_forward*
 };
 
 struct skyjo_vec_snapshot {
@@ -246,6 +259,10 @@ static void next_deal_tag(skyjo_vec *h, bool flip_list) {
 // published at the start of the next cycle (one dealing interval later), long before a bank of SK_BANK runs dry.
 int start_deals(skyjo_vec *h, hipStream_t s) {
   int rc;
+  if (h->no_bank) {  // nothing is ever dealt ahead: a reset deals in place (deal_inline)
+    h->pending_iters = 0;
+    return SKYJO_OK;
+  }
   if ((rc = publish_deals(h, s))) return rc;
   adapt_interval(h);
   next_deal_tag(h, true);
@@ -277,7 +294,7 @@ int start_deals(skyjo_vec *h, hipStream_t s) {
 // The pipelined form of a dealing cycle beside the step kernel (skyjo_device.h, sk_plan_deals): plan_cycle() before the
 // step launch after which the run is due - that launch plans the run on its way out -, start_deals_piped() after it:
 // the dealing kernel goes to its own stream behind an event for that launch.  Nothing on the caller's stream waits.
-static bool piped_mode(const skyjo_vec *h) { return h->overlap && h->piped; }
+static bool piped_mode(const skyjo_vec *h) { return h->overlap && h->piped && !h->no_bank; }
 static void plan_cycle(skyjo_vec *h) {
   next_deal_tag(h, false);
   h->P.plan_new_tag = h->deal_tag;
@@ -296,7 +313,8 @@ int start_deals_piped(skyjo_vec *h, hipStream_t s) {
 }
 
 int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions, uint8_t *rec, int32_t *act_out,
-                int iters, uint64_t policy_seed, double *end_rew = nullptr, uint8_t *end_flag = nullptr) {
+                int iters, uint64_t policy_seed, double *end_rew = nullptr, uint8_t *end_flag = nullptr, uint8_t *raw_out = nullptr) {
+  h->raw_valid = false;  // (the host's copy of the games is stale from here on; step_host sets it again)
   dim3 grid(h->P.tiles), block(SK_TILE);
   const bool ind = h->P.L.indirect != 0;
   int rc;
@@ -304,8 +322,8 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
   if ((rc = prof_events(h, 0, &e0, &e1))) return rc;
   if (h->deal_inflight && h->inflight_piped) h->P.ov_flags |= 1u;  // publish what has been dealt since (sk_publish_deals)
 #define LAUNCH3(I, Pol, NP)                                                                                       \
-  hipExtLaunchKernelGGL((k_step<I, Pol, NP>), grid, block, (uint32_t)h->lds_bytes, s, e0, e1, 0, h->P, actions,   \
-                        rec, act_out, iters, policy_seed, h->iter, end_rew, end_flag)
+  hipExtLaunchKernelGGL((k_step<I, Pol, NP>), grid, block, (uint32_t)(Pol ? h->lds_rollout : h->lds_bytes), s, e0, e1, 0, h->P, actions,   \
+                        rec, act_out, iters, policy_seed, h->iter, end_rew, end_flag, raw_out, h->raw_stride)
 #define LAUNCH(I, Pol)                                \
   switch (h->P.L.N) {                                 \
     case 2: LAUNCH3(I, Pol, 2); break;                \
@@ -337,14 +355,20 @@ int fetch_record(skyjo_vec *h, const uint4 *base, int game, std::vector<uint8_t>
 }
 
 // One launch of the policy net (nets == 2: policy and value branch over the same records, grid.y = 2) in the net's precision.
+// `prof`: the engine whose kernel timing (skyjo_vec_profile, slot 4) collects this launch, or null.
 int launch_mlp(const SkMlpDev &a, const SkMlpDev &b, int nets, const uint8_t *rec, int rec_bytes, int obs_dim, int64_t n, float *out_a,
-               const SkMlpDraw &draw, float *out_b, hipStream_t s) {
+               const SkMlpDraw &draw, float *out_b, hipStream_t s, skyjo_vec *prof = nullptr) {
   const dim3 grid((unsigned)((n + 32 * SKP_GT * SKP_WG - 1) / (32 * SKP_GT * SKP_WG)), (unsigned)nets), block(64 * SKP_WG);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (prof) {
+    int rc = prof_events(prof, 4, &e0, &e1);
+    if (rc) return rc;
+  }
   if (a.split) {
     static_assert(SKP_GT == 1, "the float32-grade kernel handles one tile of 32 games per wavefront");
-    hipLaunchKernelGGL(k_mlp_forward_split, grid, block, 0, s, a, rec, rec_bytes, obs_dim, (long long)n, out_a, draw, b, out_b);
+    hipExtLaunchKernelGGL(k_mlp_forward_split, grid, block, 0, s, e0, e1, 0, a, rec, rec_bytes, obs_dim, (long long)n, out_a, draw, b, out_b);
   } else {
-    hipLaunchKernelGGL(k_mlp_forward, grid, block, 0, s, a, rec, rec_bytes, obs_dim, (long long)n, out_a, draw, b, out_b);
+    hipExtLaunchKernelGGL(k_mlp_forward, grid, block, 0, s, e0, e1, 0, a, rec, rec_bytes, obs_dim, (long long)n, out_a, draw, b, out_b);
   }
   HIPCHK(hipGetLastError());
   return SKYJO_OK;
@@ -396,7 +420,10 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   // aliases this area) + per-lane per-seat float64 statistics
   h->lds_bytes = h->lds_tile + (size_t)SK_TILE * (P.L.indirect ? 64 : P.L.rec_bytes + 16) + (size_t)SK_ACC_KINDS * cfg->num_players * 512 +
                  (cfg->num_players < 8 ? (size_t)cfg->num_players * 1024 : 0);  // + the card chunks of games waiting to be scored
-  if (const char *e = getenv("SKYJO_LDS_PAD")) h->lds_bytes += (size_t)atoi(e);  // diagnostic: caps the wavefronts per CU
+  h->lds_rollout = (cfg->num_players >= 2 && cfg->num_players <= 4)
+                       ? h->lds_tile + (size_t)SK_TILE * (P.L.indirect ? 64 : P.L.rec_bytes + 16) + (size_t)cfg->num_players * 1024
+                       : h->lds_bytes;
+  if (const char *e = getenv("SKYJO_LDS_PAD")) h->lds_bytes += (size_t)atoi(e), h->lds_rollout += (size_t)atoi(e);  // diagnostic: caps the wavefronts per CU
   const size_t rec16 = (size_t)P.tiles * P.L.chunks * SK_TILE;
   if ((uint64_t)SK_BANK * rec16 * 16 >= (1ull << 32)) {  // (LDS-DMA addresses the bank with 32-bit offsets)
     delete h;
@@ -462,6 +489,20 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     h->health_host[0] = h->health_host[1] = h->health_host[2] = h->health_host[3] = 0;
     P.health_host = (volatile uint32_t *)dp;
   }
+  h->raw_stride = (int)((P.L.state_bytes + 16 * cfg->num_players + 8 + 15) & ~15);
+  if (h->G <= 4096) {  // small batches: the *_host calls go through host-mapped memory (see the handle's fields)
+    const size_t a = (h->G * 4 + 255) & ~(size_t)255, m = (h->G + 255) & ~(size_t)255, r = (h->G * (size_t)P.L.rec_bytes + 255) & ~(size_t)255,
+                 w = h->G * (size_t)h->raw_stride;
+    void *dp = nullptr;
+    if (hipHostMalloc((void **)&h->hm_block, a + m + r + w, hipHostMallocMapped) == hipSuccess &&
+        hipHostGetDevicePointer(&dp, h->hm_block, 0) == hipSuccess) {
+      memset(h->hm_block, 0, a + m + r + w);
+      uint8_t *d = (uint8_t *)dp;
+      h->hm_actions = (int32_t *)h->hm_block, h->hm_mask = h->hm_block + a, h->hm_records = h->hm_block + a + m, h->hm_raw = h->hm_block + a + m + r;
+      h->hm_actions_d = (int32_t *)d, h->hm_mask_d = d + a, h->hm_records_d = d + a + m, h->hm_raw_d = d + a + m + r;
+      h->fast_host = !getenv("SKYJO_NO_FAST_HOST");
+    }
+  }
   // The dealing kernel runs beside the step kernel (own stream) when the batch leaves SIMDs free: up to 768 tiles of
   // the 1024 one-wavefront-per-SIMD slots (three-player games, beside / in line, x 10^9 steps/s: 32 768: 17.1 / 15.5,
   // 49 152: 23.1 / 22.6, 57 344: 25.2 / 26.1, 65 536: 20.3 / 29.0 - on a full chip the two kernels compete for the same
@@ -490,6 +531,7 @@ int skyjo_vec_destroy(skyjo_vec *h) {
   for (auto &v : h->ev)
     for (auto &e : v) (void)hipEventDestroy(e.first), (void)hipEventDestroy(e.second);
   if (h->health_host) (void)hipHostFree(h->health_host);
+  if (h->hm_block) (void)hipHostFree(h->hm_block);
   delete h;
   return SKYJO_OK;
 }
@@ -506,6 +548,7 @@ int skyjo_vec_seed(skyjo_vec *h, const uint64_t *seeds_host, uint64_t base_seed,
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
   hipStream_t s = (hipStream_t)stream;
   GUARD(h);
+  h->raw_valid = false;
   uint64_t *d_seeds = nullptr;
   if (seeds_host) {
     HIPCHK(hipMalloc((void **)&d_seeds, sizeof(uint64_t) * (size_t)h->P.B));
@@ -542,6 +585,7 @@ int skyjo_vec_seed_one(skyjo_vec *h, int32_t game, uint64_t value, void *stream)
   if (!h || game < 0 || game >= h->P.B) return fail(SKYJO_E_INVALID, "bad argument");
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   GUARD(h);
+  h->raw_valid = false;
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if ((rc = ensure_scratch(h)) || (rc = publish_deals(h, s))) return rc;  // nobody else may be using the stream that is re-seeded
@@ -627,6 +671,7 @@ int skyjo_vec_snapshot_restore(skyjo_vec *h, const skyjo_vec_snapshot *sn, void 
   h->deal_tag = sn->deal_tag, h->P.deal_tag = sn->deal_tag, h->iter = sn->iter, h->iters_total = sn->iters_total;
   h->health_host[0] = sn->health[0], h->health_host[1] = sn->health[1];
   h->deal_inflight = false, h->inflight_piped = false;
+  h->raw_valid = false;
   return SKYJO_OK;
 }
 
@@ -644,27 +689,32 @@ int skyjo_vec_snapshot_destroy(skyjo_vec_snapshot *sn) {
   return SKYJO_OK;
 }
 
-int skyjo_vec_reset(skyjo_vec *h, const uint8_t *mask, void *records_out, void *stream) {
-  if (!h) return fail(SKYJO_E_INVALID, "null handle");
-  GUARD(h);
-  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
-  hipStream_t s = (hipStream_t)stream;
+static int reset_impl(skyjo_vec *h, const uint8_t *mask, void *records_out, hipStream_t s, uint8_t *raw_out) {
   int rc;
+  h->raw_valid = false;
   if ((rc = publish_deals(h, s))) return rc;  // make every dealt episode available
   dim3 grid(h->P.tiles), block(SK_TILE);
   if (h->P.L.indirect)
-    hipLaunchKernelGGL((k_reset<true>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out);
+    hipLaunchKernelGGL((k_reset<true>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out, raw_out, h->raw_stride);
   else
-    hipLaunchKernelGGL((k_reset<false>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out);
+    hipLaunchKernelGGL((k_reset<false>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out, raw_out, h->raw_stride);
   HIPCHK(hipGetLastError());
   if ((rc = start_deals(h, s))) return rc;  // refill what was taken (one episode per game and cycle)
   return publish_deals(h, s);
 }
 
-static int step_once(skyjo_vec *h, const int32_t *actions, void *records_out, double *end_rew, uint8_t *end_flag, hipStream_t s) {
+int skyjo_vec_reset(skyjo_vec *h, const uint8_t *mask, void *records_out, void *stream) {
+  if (!h) return fail(SKYJO_E_INVALID, "null handle");
+  GUARD(h);
+  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  return reset_impl(h, mask, records_out, (hipStream_t)stream, nullptr);
+}
+
+static int step_once(skyjo_vec *h, const int32_t *actions, void *records_out, double *end_rew, uint8_t *end_flag, hipStream_t s,
+                     uint8_t *raw_out = nullptr) {
   const bool due = h->pending_iters + 1 >= h->deal_every_iters, piped = piped_mode(h);
   if (due && piped) plan_cycle(h);
-  int rc = launch_step(h, s, false, actions, (uint8_t *)records_out, nullptr, 1, 0, end_rew, end_flag);
+  int rc = launch_step(h, s, false, actions, (uint8_t *)records_out, nullptr, 1, 0, end_rew, end_flag, raw_out);
   if (rc) return rc;
   if (due) return piped ? start_deals_piped(h, s) : start_deals(h, s);
   return SKYJO_OK;
@@ -708,7 +758,7 @@ int skyjo_vec_model_rollout(skyjo_vec *h, const skyjo_vec_mlp *policy, const sky
     d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = first_ticket + (uint64_t)t;
     d.game_id0 = h->P.game_id0, d.actions = b->actions + (size_t)t * B, d.logp = b->logp ? b->logp + (size_t)t * B : nullptr;
     if ((rc = launch_mlp(policy->net, value ? value->net : policy->net, value ? 2 : 1, rec + (size_t)t * B * rb, (int)rb, policy->obs_dim,
-                         (int64_t)B, nullptr, d, value ? b->values + (size_t)t * B * vd : nullptr, s)))
+                         (int64_t)B, nullptr, d, value ? b->values + (size_t)t * B * vd : nullptr, s, h)))
       return rc;
     if ((rc = step_once(h, b->actions + (size_t)t * B, rec + (size_t)(t + 1) * B * rb,
                         b->final_rewards ? b->final_rewards + (size_t)t * B * N : nullptr, b->episode_end ? b->episode_end + (size_t)t * B : nullptr, s)))
@@ -974,14 +1024,8 @@ int skyjo_vec_reset_counters(skyjo_vec *h, void *stream) {
   return SKYJO_OK;
 }
 
-int skyjo_vec_get_state(skyjo_vec *h, int32_t game, skyjo_game_state *o, void *stream) {
-  if (!h || !o || game < 0 || game >= h->P.B) return fail(SKYJO_E_INVALID, "bad argument");
-  GUARD(h);
-  hipStream_t s = (hipStream_t)stream;
-  const SkLayout &L = h->P.L;
-  std::vector<uint8_t> r;
-  int rc = fetch_record(h, h->P.state, game, r, s);
-  if (rc) return rc;
+// raw packed record (skyjo_layout.h) -> the canonical form of include/skyjo_vec.h (rewards / final_score are filled by the caller)
+static void decode_state(const SkLayout &L, const uint8_t *r, skyjo_game_state *o) {
   memset(o, 0, sizeof(*o));
   for (int p = 0; p < L.N; p++)
     for (int k = 0; k < 12; k++) {
@@ -1007,6 +1051,27 @@ int skyjo_vec_get_state(skyjo_vec *h, int32_t game, skyjo_game_state *o, void *s
     memcpy(&pl, &r[sk_pb(L, p) + PB_PLACED], 2);
     o->num_placed[p] = pl;
   }
+}
+
+int skyjo_vec_get_state(skyjo_vec *h, int32_t game, skyjo_game_state *o, void *stream) {
+  if (!h || !o || game < 0 || game >= h->P.B) return fail(SKYJO_E_INVALID, "bad argument");
+  GUARD(h);
+  hipStream_t s = (hipStream_t)stream;
+  const SkLayout &L = h->P.L;
+  if (h->raw_valid) {  // the last *_host call brought every game back with its records: no device traffic
+    const uint8_t *raw = h->hm_raw + (size_t)game * h->raw_stride;
+    decode_state(L, raw, o);
+    const double *d = (const double *)(raw + L.state_bytes);
+    if (o->done) {
+      memcpy(o->rewards, d, sizeof(double) * L.N);
+      if (o->is_terminated) memcpy(o->final_score, d + L.N, sizeof(double) * L.N);
+    }
+    return dev_error_check(h);
+  }
+  std::vector<uint8_t> r;
+  int rc = fetch_record(h, h->P.state, game, r, s);
+  if (rc) return rc;
+  decode_state(L, r.data(), o);
   if (o->done) {
     HIPCHK(hipMemcpyAsync(o->rewards, h->P.rewards + (size_t)game * L.N, sizeof(double) * L.N, hipMemcpyDeviceToHost, s));
     if (o->is_terminated)
@@ -1021,6 +1086,7 @@ int skyjo_vec_set_state(skyjo_vec *h, int32_t game, const skyjo_game_state *in, 
   if (!h || !in || game < 0 || game >= h->P.B) return fail(SKYJO_E_INVALID, "bad argument");
   GUARD(h);
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  h->raw_valid = false;
   const SkLayout &L = h->P.L;
   if (in->n_draw < 0 || in->n_disc < 0 || in->n_draw + in->n_disc > SK_NCARDS)
     return fail(SKYJO_E_INVALID, "pile sizes out of range");
@@ -1090,6 +1156,7 @@ int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream)
   GUARD(h);
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   if (h->P.rng_mode != SKYJO_RNG_MT19937) return fail(SKYJO_E_STATE, "seed_raw needs the MT19937 mode");
+  h->raw_valid = false;
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if ((rc = publish_deals(h, s))) return rc;  // nobody else may be using the stream that is re-seeded
@@ -1097,6 +1164,51 @@ int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream)
   HIPCHK(hipGetLastError());
   if ((rc = start_deals(h, s))) return rc;
   return publish_deals(h, s);
+}
+
+int skyjo_vec_rng_set_state(skyjo_vec *h, int32_t game, const uint32_t *key_host, int32_t pos, void *stream) {
+  if (!h || !key_host || game < 0 || game >= h->P.B || pos < 0 || pos > 624) return fail(SKYJO_E_INVALID, "bad argument");
+  GUARD(h);
+  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  if (h->P.rng_mode != SKYJO_RNG_MT19937 || !h->no_bank)
+    return fail(SKYJO_E_STATE, "skyjo_vec_rng_set_state needs the MT19937 mode and SKYJO_OPT_NO_BANK (episodes dealt ahead would belong to the old stream)");
+  hipStream_t s = (hipStream_t)stream;
+  // numpy's (key, pos): the words from pos on are regenerated and unconsumed, everything is of one generation - in the
+  // engine's terms position pos with 624 - pos words regenerated ahead (MtStream: idx | ahead << 16); pos == 624 is a fresh block
+  const int32_t packed = pos >= 624 ? 0 : (pos | ((624 - pos) << 16));
+  HIPCHK(hipMemcpyAsync(h->P.mt + (size_t)game * 624, key_host, 624 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(h->P.mt_idx + game, &packed, sizeof(packed), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));  // (`packed` lives on this stack frame, `key_host` belongs to the caller)
+  return SKYJO_OK;
+}
+
+int skyjo_vec_rng_get_state(skyjo_vec *h, int32_t game, uint32_t *key_out_host, int32_t *pos_out_host, void *stream) {
+  if (!h || !key_out_host || !pos_out_host || game < 0 || game >= h->P.B) return fail(SKYJO_E_INVALID, "bad argument");
+  GUARD(h);
+  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  if (h->P.rng_mode != SKYJO_RNG_MT19937 || !h->no_bank)
+    return fail(SKYJO_E_STATE, "skyjo_vec_rng_get_state needs the MT19937 mode and SKYJO_OPT_NO_BANK");
+  hipStream_t s = (hipStream_t)stream;
+  int32_t packed = 0;
+  HIPCHK(hipMemcpyAsync(key_out_host, h->P.mt + (size_t)game * 624, 624 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(&packed, h->P.mt_idx + game, sizeof(packed), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  int idx = packed & 0xffff, ahead = packed >> 16;
+  if (idx >= 624) idx = 0;
+  if (idx + ahead > 624) return fail(SKYJO_E_STATE, "the stream's regenerated window wraps: not a numpy state (cannot happen without a bank)");
+  if (idx == 0 && ahead == 0) {  // everything consumed, nothing of the next block made yet: numpy's pos == 624
+    *pos_out_host = 624;
+    return SKYJO_OK;
+  }
+  // The engine regenerates lazily, 16 words at a time; numpy makes the whole block at once.  Finish the block: words
+  // idx + ahead .. 623 from the old word, its successor and the (already new, for i >= 227) word 397 further on.
+  uint32_t *mt = key_out_host;
+  for (int i = idx + ahead; i < 624; i++) {
+    const uint32_t y = (mt[i] & 0x80000000u) | (mt[i + 1 == 624 ? 0 : i + 1] & 0x7fffffffu);
+    mt[i] = mt[i + 397 >= 624 ? i + 397 - 624 : i + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  }
+  *pos_out_host = idx;
+  return SKYJO_OK;
 }
 
 int skyjo_vec_profile(skyjo_vec *h, int enable, double ms_out[SKYJO_PROF_KERNELS], int64_t launches_out[SKYJO_PROF_KERNELS]) {
@@ -1137,6 +1249,7 @@ int skyjo_vec_get_option(const skyjo_vec *h, int option, int64_t *value_out) {
   switch (option) {
     case SKYJO_OPT_DEAL_INTERVAL: *value_out = h->deal_every_iters; return SKYJO_OK;
     case SKYJO_OPT_OVERLAP: *value_out = h->overlap ? 1 : 0; return SKYJO_OK;
+    case SKYJO_OPT_NO_BANK: *value_out = h->no_bank ? 1 : 0; return SKYJO_OK;
     default: return fail(SKYJO_E_INVALID, "unknown option");
   }
 }
@@ -1158,6 +1271,10 @@ int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
       if (h->auto_interval) h->deal_every_iters = h->interval_default;
       return SKYJO_OK;
     }
+    case SKYJO_OPT_NO_BANK:
+      if (h->seeded) return fail(SKYJO_E_STATE, "SKYJO_OPT_NO_BANK must be set before skyjo_vec_seed");
+      h->no_bank = value != 0;
+      return SKYJO_OK;
     case SKYJO_OPT_DEBUG_SPIN_LOG2:
       if (value < 1 || value > 30) return fail(SKYJO_E_INVALID, "spin limit must be 2^1 .. 2^30");
       h->P.spin_log2 = (uint32_t)value;
@@ -1183,6 +1300,16 @@ static int ensure_scratch(skyjo_vec *h) {
 int skyjo_vec_step_host(skyjo_vec *h, const int32_t *actions_host, void *records_out_host) {
   if (!h || !actions_host) return fail(SKYJO_E_INVALID, "null argument");
   GUARD(h);
+  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  if (h->fast_host) {  // actions read from / records and whole games written to host-mapped memory: one launch, one synchronisation
+    memcpy(h->hm_actions, actions_host, sizeof(int32_t) * (size_t)h->P.B);
+    int rc = step_once(h, h->hm_actions_d, h->hm_records_d, nullptr, nullptr, nullptr, h->hm_raw_d);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    h->raw_valid = true;
+    if (records_out_host) memcpy(records_out_host, h->hm_records, (size_t)h->P.B * h->P.L.rec_bytes);
+    return dev_error_check(h);
+  }
   int rc = ensure_scratch(h);
   if (rc) return rc;
   HIPCHK(hipMemcpy(h->d_actions, actions_host, sizeof(int32_t) * (size_t)h->P.B, hipMemcpyHostToDevice));
@@ -1197,6 +1324,14 @@ int skyjo_vec_step_host(skyjo_vec *h, const int32_t *actions_host, void *records
 int skyjo_vec_observe_host(skyjo_vec *h, const int32_t *players_host, void *records_out_host) {
   if (!h || !records_out_host) return fail(SKYJO_E_INVALID, "null argument");
   GUARD(h);
+  if (h->fast_host) {  // (the games do not change: a valid host copy of them stays valid)
+    if (players_host) memcpy(h->hm_actions, players_host, sizeof(int32_t) * (size_t)h->P.B);
+    int rc = skyjo_vec_observe(h, players_host ? h->hm_actions_d : nullptr, h->hm_records_d, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    memcpy(records_out_host, h->hm_records, (size_t)h->P.B * h->P.L.rec_bytes);
+    return dev_error_check(h);
+  }
   int rc = ensure_scratch(h);
   if (rc) return rc;
   if (players_host)
@@ -1209,6 +1344,16 @@ int skyjo_vec_observe_host(skyjo_vec *h, const int32_t *players_host, void *reco
 int skyjo_vec_reset_host(skyjo_vec *h, const uint8_t *mask_host, void *records_out_host) {
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
   GUARD(h);
+  if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
+  if (h->fast_host) {
+    if (mask_host) memcpy(h->hm_mask, mask_host, (size_t)h->P.B);
+    int rc = reset_impl(h, mask_host ? h->hm_mask_d : nullptr, h->hm_records_d, nullptr, h->hm_raw_d);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    h->raw_valid = true;
+    if (records_out_host) memcpy(records_out_host, h->hm_records, (size_t)h->P.B * h->P.L.rec_bytes);
+    return dev_error_check(h);
+  }
   int rc = ensure_scratch(h);
   if (rc) return rc;
   if (mask_host) HIPCHK(hipMemcpy(h->d_mask, mask_host, (size_t)h->P.B, hipMemcpyHostToDevice));
@@ -1224,6 +1369,16 @@ int skyjo_vec_get_rewards_host(skyjo_vec *h, double *rewards_out, double *scores
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
   GUARD(h);
   const size_t n = (size_t)h->P.B * h->P.L.N;
+  if (h->raw_valid) {  // served from what the last *_host call brought back
+    const size_t N = (size_t)h->P.L.N;
+    for (int g = 0; g < h->P.B; g++) {
+      const uint8_t *raw = h->hm_raw + (size_t)g * h->raw_stride + h->P.L.state_bytes;
+      if (rewards_out) memcpy(rewards_out + g * N, raw, 8 * N);
+      if (scores_out) memcpy(scores_out + g * N, raw + 8 * N, 8 * N);
+      if (done_out) done_out[g] = raw[16 * N + 4];
+    }
+    return dev_error_check(h);
+  }
   if (rewards_out) HIPCHK(hipMemcpy(rewards_out, h->P.rewards, n * sizeof(double), hipMemcpyDeviceToHost));
   if (scores_out) HIPCHK(hipMemcpy(scores_out, h->P.scores, n * sizeof(double), hipMemcpyDeviceToHost));
   if (done_out) HIPCHK(hipMemcpy(done_out, h->P.done, (size_t)h->P.B, hipMemcpyDeviceToHost));

@@ -624,8 +624,12 @@ __device__ __forceinline__ void finish_game(const SkParams &P, uint8_t *lp, uint
 
 // The same for a compile-time player count: card rows come in as dwords, scores stay in registers.  `rows`: this lane's
 // card chunk of player 0, player p's `stride` bytes further - the live tile, or the copy a deferred scoring works on.
+// `racc` != nullptr: the per-seat statistics are kept in the lane's REGISTERS (SK_ACC_KINDS x NP doubles, constant indices
+// after unrolling) instead of the LDS slots behind `ap` - the fused rollout kernels, whose LDS footprint decides how many
+// dealing wavefronts fit beside them on a CU (25 KB instead of 31 KB at three players).
 template <int NP>
-__device__ __forceinline__ void finish_game_fixed(const SkParams &P, const uint8_t *rows, int stride, uint8_t *ap, int g, int finisher) {
+__device__ __forceinline__ void finish_game_fixed(const SkParams &P, const uint8_t *rows, int stride, uint8_t *ap, int g, int finisher,
+                                                  double *racc = nullptr) {
   double *sc = P.scores + (size_t)g * NP, *rw = P.rewards + (size_t)g * NP;
   int s[NP], refunded[NP];
   int mn = 0, fs = 0;
@@ -658,7 +662,11 @@ __device__ __forceinline__ void finish_game_fixed(const SkParams &P, const uint8
     double r = (-d[p] + mean) + P.mean_reward;
     if (P.reward_refunded != 0.0) r += (double)refunded[p] * P.reward_refunded;
     sc[p] = d[p], rw[p] = r;
-    acc_episode(ap, NP, p, d[p], r, refunded[p]);
+    if (racc) {
+      racc[p] += d[p], racc[NP + p] += r, racc[2 * NP + p] += r * r, racc[3 * NP + p] += (double)refunded[p];
+    } else {
+      acc_episode(ap, NP, p, d[p], r, refunded[p]);
+    }
   }
 }
 
@@ -758,7 +766,7 @@ __device__ __forceinline__ int policy_pick(int phase, const ObsRegs &o, uint32_t
 template <bool INDIRECT, int NP, bool TRUSTED>
 __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uint8_t *fp, uint8_t *ap, HdrRegs &h, uint32_t v0,
                                              uint32_t v1, uint32_t v2, int a, int g, LaneCounters &cnt, Stamps &st,
-                                             uint8_t *pendp, int &pend_fin, const uint4 &row_pre) {
+                                             uint8_t *pendp, int &pend_fin, const uint4 &row_pre, double *racc = nullptr) {
   const int N = P.L.N;
   const int phase = h.w0 & 0xff, p = (h.w0 >> 8) & 0xff;
   const int blk = sk_pb(P.L, p), cardb = blk + PB_CARDS, visb = blk + PB_VIS, pb = P.L.off_pile;
@@ -775,7 +783,13 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
   if (!legal) {  // offender gets illegal_reward, everybody else 0, all done
     double *rw = P.rewards + (size_t)g * N;
     for (int q = 0; q < N; q++) rw[q] = q == p ? P.illegal_reward : 0.0;
-    acc_add(ap, N + p, P.illegal_reward), acc_add(ap, 2 * N + p, P.illegal_reward * P.illegal_reward);
+    if (NP > 0 && racc) {
+#pragma unroll
+      for (int q = 0; q < (NP > 0 ? NP : 1); q++)
+        racc[NP + q] += q == p ? P.illegal_reward : 0.0, racc[2 * NP + q] += q == p ? P.illegal_reward * P.illegal_reward : 0.0;
+    } else {
+      acc_add(ap, N + p, P.illegal_reward), acc_add(ap, 2 * N + p, P.illegal_reward * P.illegal_reward);
+    }
     h.w0 = (h.w0 & 0x0000ffffu) | ((((h.w0 >> 16) & 0xffu) | F_DONE) << 16) | ((uint32_t)SKYJO_ST_ILLEGAL << 24);
     P.done[g] = 1;
     cnt.illegal++;
@@ -812,7 +826,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
           for (int q = 0; q < NQ; q++) *(uint4 *)(pendp + q * 1024) = LQ(sk_pb(P.L, q) >> 4);
           pend_fin = p;
         } else {
-          finish_game_fixed<NQ>(P, lp + (P.L.off_players >> 4) * 1024, 2048, ap, g, p);
+          finish_game_fixed<NQ>(P, lp + (P.L.off_players >> 4) * 1024, 2048, ap, g, p, racc);
         }
       } else {
         finish_game(P, lp, fp, ap, g, p);
@@ -1137,10 +1151,23 @@ __device__ __forceinline__ void sk_plan_deals(const SkParams &P, int g) {
   if (be && threadIdx.x == 0) atomicAdd(P.bank_empty + (P.plan_new_tag & 1u), (uint32_t)__popcll(be));  // (rare)
 }
 
+// Small batches, host-style calls (single-game views): the lane hands its whole game to the host with the records - the
+// packed record as it lies in LDS (chunk c at byte 16 c), then rewards[N], scores[N] (float64), the stream position word
+// and the done byte - into host-mapped memory, so that skyjo_vec_get_state / get_rewards_host after a *_host call cost
+// no device traffic at all (skyjo_capi.hip: raw_valid).
+__device__ __forceinline__ void sk_export_raw(const SkParams &P, uint8_t *lp, int g, uint8_t *o) {
+  for (int c = 0; c < P.L.chunks; c++) ((uint4 *)o)[c] = LQ(c);
+  double *d = (double *)(o + P.L.state_bytes);
+  for (int p = 0; p < P.L.N; p++) d[p] = P.rewards[(size_t)g * P.L.N + p], d[P.L.N + p] = P.scores[(size_t)g * P.L.N + p];
+  uint32_t *m = (uint32_t *)(d + 2 * P.L.N);
+  m[0] = P.rng_mode == SKYJO_RNG_MT19937 ? (uint32_t)P.mt_idx[g] : 0u;
+  m[1] = P.done[g];
+}
+
 template <bool INDIRECT, bool POLICY, int NP>
 __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *actions, uint8_t *rec_out,
                                                   int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0,
-                                                  double *end_rew_out, uint8_t *end_out) {
+                                                  double *end_rew_out, uint8_t *end_out, uint8_t *raw_out, int raw_stride) {
   SkParams P = Pin;
   if (NP > 0) P.L = sk_make_layout(NP, INDIRECT ? 1 : 0);  // same values as the host computed, now constants
   extern __shared__ uint32_t lds_raw[];
@@ -1154,11 +1181,20 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   uint8_t *stg = (uint8_t *)lds_raw + P.L.chunks * 1024;
   uint8_t *fp = stg + lane * 4;
   uint8_t *ap = stg + (INDIRECT ? 4096 : SK_TILE * (P.L.rec_bytes + 16)) + lane * 8;
-  // deferred scoring (fixed player counts under the on-device policy): one card chunk per player and lane behind the statistics
+  // deferred scoring (fixed player counts under the on-device policy): one card chunk per player and lane.  Those kernels
+  // keep the per-seat statistics in registers (REGACC) - their LDS is tile | staging | card chunks, nothing else: at three
+  // players 25 KB per wavefront, so that four dealing wavefronts (14.75 KB each) fit beside a CU's four step wavefronts.
   constexpr bool DEFER = POLICY && NP > 0 && NP < 8;
-  uint8_t *pendp = DEFER ? stg + (INDIRECT ? 4096 : SK_TILE * (P.L.rec_bytes + 16)) + SK_ACC_KINDS * P.L.N * 512 + lane * 16 : nullptr;
+  constexpr bool REGACC = DEFER;
+  constexpr int NACC = REGACC ? SK_ACC_KINDS * NP : 1;
+  double racc_store[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; k++) racc_store[k] = 0.0;
+  double *racc = REGACC ? racc_store : nullptr;
+  uint8_t *pendp = DEFER ? stg + (INDIRECT ? 4096 : SK_TILE * (P.L.rec_bytes + 16)) + (REGACC ? 0 : SK_ACC_KINDS * P.L.N * 512) + lane * 16 : nullptr;
   int pend_fin = -1;
-  for (int k = 0; k < SK_ACC_KINDS * P.L.N; k++) ACC(k) = 0.0;
+  if (!REGACC)
+    for (int k = 0; k < SK_ACC_KINDS * P.L.N; k++) ACC(k) = 0.0;
   STAMP_DECL;
 #ifdef SK_STEP_PRIO
   __builtin_amdgcn_s_setprio(SK_STEP_PRIO);  // ahead of a dealing wavefront that shares the SIMD
@@ -1214,7 +1250,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
 #ifndef SK_STAMPS_FINE
         STAMP(3);
 #endif
-        apply_action<INDIRECT, NP, POLICY>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st, pendp, pend_fin, row_pre);
+        apply_action<INDIRECT, NP, POLICY>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st, pendp, pend_fin, row_pre, racc);
 #ifdef SK_STAMPS_FINE
         STAMP(6);
 #else
@@ -1290,7 +1326,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
       // not end before its last service point - the host never sees an unscored finished game.
       if (SK_RARE(__any(pend_fin >= 0))) {
         if (pend_fin >= 0) {
-          finish_game_fixed<(NP > 0 && NP < 8) ? NP : 1>(P, pendp, 1024, ap, g, pend_fin);
+          finish_game_fixed<(NP > 0 && NP < 8) ? NP : 1>(P, pendp, 1024, ap, g, pend_fin, racc);
           pend_fin = -1;
         }
       }
@@ -1362,6 +1398,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   }
   HDR_FLUSH(h);
   tile_store_nt(P, P.state, tile, lane, lp);
+  if (!POLICY && raw_out && valid) sk_export_raw(P, lp, g, raw_out + (size_t)g * raw_stride);
   if (P.ov_flags & 2u) {
     // (first what the run beside THIS launch has dealt: a game whose busy mark outlived the launch in which it is dealt would
     // get a new episode only every second run.  The dealing kernel was started before this launch and is as good as through:
@@ -1387,11 +1424,21 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   // per-seat statistics of this launch: one slot per tile
   if (__any(cnt.episodes | cnt.illegal)) {
     double mine = 0.0;
-    for (int k = 0; k < SK_ACC_KINDS * P.L.N; k++) {
-      double x = ACC(k);
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-      x = __shfl(x, 0, 64);
-      mine = lane == k ? x : mine;
+    if (REGACC) {
+#pragma unroll
+      for (int k = 0; k < NACC; k++) {
+        double x = racc_store[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        x = __shfl(x, 0, 64);
+        mine = lane == k ? x : mine;
+      }
+    } else {
+      for (int k = 0; k < SK_ACC_KINDS * P.L.N; k++) {
+        double x = ACC(k);
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        x = __shfl(x, 0, 64);
+        mine = lane == k ? x : mine;
+      }
     }
     if (lane < SK_ACC_KINDS * P.L.N)  // lane = kind * N + seat -> slot kind * 12 + seat of the tile
       P.acc_tile[(size_t)tile * SK_ACC_KINDS * SKYJO_MAX_PLAYERS + (lane / P.L.N) * SKYJO_MAX_PLAYERS + lane % P.L.N] += mine;
@@ -1419,7 +1466,7 @@ __global__ __launch_bounds__(SK_TILE) void k_observe(SkParams P, const int32_t *
 
 // SkyjoGame.reset for the masked games: take the pre-dealt episode.
 template <bool INDIRECT>
-__global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *mask, uint8_t *rec_out) {
+__global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *mask, uint8_t *rec_out, uint8_t *raw_out, int raw_stride) {
   extern __shared__ uint32_t lds_raw[];
   const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 16;
@@ -1441,6 +1488,7 @@ __global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *ma
     emit_record<INDIRECT>(P, lp, h, ob, -1, rec_out + (size_t)g * P.L.rec_bytes);
   }
   if (want) tile_store(P, P.state, tile, lane, lp);
+  if (raw_out && (LB(H_FLAGS) & F_VALID)) sk_export_raw(P, lp, g, raw_out + (size_t)g * raw_stride);
   const unsigned long long wb = __ballot(want);
   if (want && lane == __ffsll((long long)wb) - 1) P.tile_counters[(size_t)tile * 8 + 3] += __popcll(wb);
 }

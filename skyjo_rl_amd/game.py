@@ -16,9 +16,20 @@ for the reference core API (rlskyjo/game/sample_game.py:5-28) run unchanged:
 step in which every other game gets ``ACTION_SKIP``), so single-game code can be pointed at any
 game of a running batch.
 
+``SkyjoGame(..., global_rng=True)`` reproduces the reference's RNG contract for single-game use: the
+reference deals and reshuffles from numpy's PROCESS-GLOBAL legacy stream (skyjo.py:49,81,94,101,135),
+the very stream ``policy_ra(obs, mask)`` without a generator draws from
+(random_admissible_policy.py:22-23), so ``np.random.seed(s)`` followed by ``sample_run`` /
+``simple_episode`` is reproducible there.  In this mode the game owns no stream: ``np.random``'s state
+is handed to the device before every call that can draw (a deal; a draw from an empty draw pile, which
+reshuffles) and taken back afterwards, and nothing is dealt ahead (the engine runs with ``no_bank``) -
+the loops of rlskyjo/game/sample_game.py:5-28 and rlskyjo/environment/vanilla_env_example.py:6-41
+replay bit for bit (tests/golden/global_*.npz).  The default (``global_rng=False``) keeps one private
+stream per game, which is what a vector of games needs.
+
 An *engine* is any object with the host-style methods of ``SkyjoVecEnv`` (seed, seed_one,
-reset_host, step_host, observe_host, rewards_host, get_state, set_state); tests inject an
-oracle-backed one to check this file without a GPU.
+reset_host, step_host, observe_host, rewards_host, get_state, set_state - and rng_set / rng_get /
+no_bank for the global-RNG mode); tests inject an oracle-backed one to check this file without a GPU.
 """
 import math
 import os
@@ -33,7 +44,7 @@ _PHASES = ("draw", "place")
 
 class SkyjoGame(object):
     def __init__(self, num_players=3, score_penalty=2, observe_other_player_indirect=False, engine=None,
-                 index=0, device=0, seed=None):
+                 index=0, device=0, seed=None, global_rng=False):
         # rlskyjo/game/skyjo.py:24-26
         assert 0 < num_players <= 12, "Skyjo can be played from 1 up to 8 (recommended) / 12 (theoretical) players"
         self.num_players = num_players
@@ -52,10 +63,20 @@ class SkyjoGame(object):
 
             engine = SkyjoVecEnv(1, num_players=num_players, score_penalty=float(score_penalty),
                                  observe_other_player_indirect=observe_other_player_indirect, device=device,
-                                 auto_reset=False)
+                                 auto_reset=False, no_bank=bool(global_rng))
         self._engine, self._i = engine, index
         assert engine.num_players == num_players and tuple(engine.obs_shape) == self.obs_shape
         self._rec = None
+        self._global_rng = bool(global_rng)
+        if self._global_rng:
+            assert getattr(engine, "no_bank", False), "global_rng needs an engine created with no_bank=True (nothing may be dealt ahead)"
+            engine.seed(np.zeros(engine.num_envs, dtype=np.uint64))  # (makes the engine usable; this private deal is thrown away)
+            self.rng = np.random.default_rng(seed)  # attribute parity (skyjo.py:86): unused, as in the reference
+            if seed is not None:
+                self.set_seed(seed)
+            else:
+                self.reset()  # skyjo.py:49: the constructor deals from the global stream where it stands
+            return
         # the reference deals in __init__ from the unseeded global RNG (skyjo.py:49): deal from entropy here
         self.set_seed(int.from_bytes(os.urandom(4), "little") if seed is None else seed)
 
@@ -81,13 +102,33 @@ class SkyjoGame(object):
         """Re-read this game from the engine (after the engine was stepped or its state injected behind the view's back)."""
         self._take(self._engine.observe_host())
 
+    # ---- the caller's stream (global_rng=True) ----------------------------------------------------
+    def _stream_to_device(self):
+        st = np.random.get_state(legacy=True)
+        self._np_tail = (st[3], st[4])  # (has_gauss, cached_gaussian: not ours to touch)
+        self._engine.rng_set(self._i, st[1], st[2])
+
+    def _stream_from_device(self):
+        key, pos = self._engine.rng_get(self._i)
+        np.random.set_state(("MT19937", key, pos) + self._np_tail)
+
     # ---- reset utils (skyjo.py:52-94) -----------------------------------------------------------
     def reset(self):
+        if self._global_rng:
+            self._stream_to_device()
         self._take(self._engine.reset_host(self._only_me(1, 0, np.uint8)))
+        if self._global_rng:
+            self._stream_from_device()
         assert self.expected_action[1] == self._name_draw, "expect to draw after reset"
 
     def set_seed(self, value):
-        """np.random.seed(value + 1) on this game's private legacy stream, then deal (skyjo.py:84-88)."""
+        """np.random.seed(value + 1) on this game's private legacy stream - on numpy's global one with global_rng=True,
+        exactly the reference's call - then deal (skyjo.py:84-88)."""
+        if self._global_rng:
+            np.random.seed(value + 1)                 # skyjo.py:92-94
+            self.rng = np.random.default_rng(value)   # skyjo.py:86
+            self.reset()
+            return
         self.rng = np.random.default_rng(value)  # kept for attribute parity; unused, as in the reference
         if self._engine.num_envs == 1:
             self._engine.seed(np.array([value], dtype=np.uint64))
@@ -124,7 +165,14 @@ class SkyjoGame(object):
                 f"illegal action {self.render_action_explainer(action_int)}."
                 f"card is already revealed: {self.players_masked[player_id]}")
         acts = self._only_me(int(action_int), self._engine.ACTION_SKIP, np.int32)  # the other games stay as they are
+        # the one step that draws random numbers: taking a card from an EMPTY draw pile reshuffles the discard pile first
+        # (skyjo.py:361-365) - with the caller's stream when that is the contract
+        lend = self._global_rng and action_int == 24 and self._state_now()["n_draw"] == 0 and self._state_now()["hand"] == 15
+        if lend:
+            self._stream_to_device()
         self._take(self._engine.step_host(acts))
+        if lend:
+            self._stream_from_device()
         assert self._rec["status"] != ST_ILLEGAL
         return self._rec["done"]
 

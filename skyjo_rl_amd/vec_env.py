@@ -61,7 +61,7 @@ class SkyjoVecEnv:
 
     def __init__(self, num_envs, num_players=3, score_penalty=2.0, observe_other_player_indirect=True,
                  mean_reward=1.0, reward_refunded=0.001, device=0, rng_mode=_lib.RNG_MT19937, auto_reset=True,
-                 game_id0=0, illegal_reward=-1.0):
+                 game_id0=0, illegal_reward=-1.0, no_bank=False):
         # same precondition and message as rlskyjo/game/skyjo.py:24-26
         assert 0 < num_players <= 12, "Skyjo can be played from 1 up to 8 (recommended) / 12 (theoretical) players"
         self._L = _lib.load()
@@ -80,6 +80,9 @@ class SkyjoVecEnv:
         self.game_id0 = int(game_id0)
         self.obs_shape = (self.obs_dim,)       # skyjo.py:43-45
         self.action_mask_shape = (26,)         # skyjo.py:46
+        self.no_bank = bool(no_bank)
+        if no_bank:  # SKYJO_OPT_NO_BANK: deals are made in place, when the reference makes them (global-RNG single-game views)
+            _lib.check(self._L.skyjo_vec_set_option(self._h, 5, 1))
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -317,21 +320,34 @@ class SkyjoVecEnv:
         _lib.check(self._L.skyjo_vec_reset_counters(self._h, None))
 
     def get_state(self, game):
-        s = _lib.GameState()
-        _lib.check(self._L.skyjo_vec_get_state(self._h, int(game), C.byref(s), None))
-        N = self.num_players
+        """Canonical form of one game (include/skyjo_vec.h: skyjo_game_state).  Right after a host-style step / reset of a
+        small batch this costs no device traffic (the call brought every game back with its records)."""
+        buf = np.zeros(1, dtype=_lib.GAME_STATE_DTYPE)
+        _lib.check(self._L.skyjo_vec_get_state(self._h, int(game), buf.ctypes.data_as(C.POINTER(_lib.GameState)), None))
+        s = buf[0]
+        N, nd, ns = self.num_players, int(s["n_draw"]), int(s["n_disc"])
         return dict(
-            cards=np.array([list(s.players_cards[p]) for p in range(N)], dtype=np.int8),
-            masked=np.array([list(s.players_masked[p]) for p in range(N)], dtype=np.int8),
-            draw=np.array(list(s.drawpile[: s.n_draw]), dtype=np.int8), n_draw=int(s.n_draw),
-            disc=np.array(list(s.discard_pile[: s.n_disc]), dtype=np.int8), n_disc=int(s.n_disc),
-            hand=int(s.hand_card), player=int(s.expected_player), phase=int(s.expected_phase),
-            is_terminated=bool(s.is_terminated), done=bool(s.done), status=int(s.status),
-            episode_steps=int(s.episode_steps), episode=int(s.episode), reshuffles=int(s.reshuffles),
-            num_refunded=np.array(s.num_refunded[:N], dtype=np.int32),
-            num_placed=np.array(s.num_placed[:N], dtype=np.int32),
-            final_score=np.array(s.final_score[:N], dtype=np.float64),
-            rewards=np.array(s.rewards[:N], dtype=np.float64))
+            cards=s["players_cards"][:N].copy(), masked=s["players_masked"][:N].copy(),
+            draw=s["drawpile"][:nd].copy(), n_draw=nd, disc=s["discard_pile"][:ns].copy(), n_disc=ns,
+            hand=int(s["hand_card"]), player=int(s["expected_player"]), phase=int(s["expected_phase"]),
+            is_terminated=bool(s["is_terminated"]), done=bool(s["done"]), status=int(s["status"]),
+            episode_steps=int(s["episode_steps"]), episode=int(s["episode"]), reshuffles=int(s["reshuffles"]),
+            num_refunded=s["num_refunded"][:N].copy(), num_placed=s["num_placed"][:N].copy(),
+            final_score=s["final_score"][:N].copy(), rewards=s["rewards"][:N].copy())
+
+    # ------------------------------------------------------------------ the caller's numpy stream (no_bank engines)
+    def rng_set(self, game, key, pos):
+        """Hand numpy's legacy stream - ``np.random.get_state()``: key uint32[624], pos - to one game (MT19937 mode, no_bank)."""
+        key = np.ascontiguousarray(key, dtype=np.uint32)
+        assert key.shape == (624,)
+        _lib.check(self._L.skyjo_vec_rng_set_state(self._h, int(game), key.ctypes.data_as(C.c_void_p), int(pos), None))
+
+    def rng_get(self, game):
+        """The game's stream in numpy's terms: (key uint32[624], pos) for ``np.random.set_state``."""
+        key = np.zeros(624, dtype=np.uint32)
+        pos = C.c_int32()
+        _lib.check(self._L.skyjo_vec_rng_get_state(self._h, int(game), key.ctypes.data_as(C.c_void_p), C.byref(pos), None))
+        return key, int(pos.value)
 
     def set_state(self, game, cards, masked, draw, disc, hand=15, player=0, phase=0, num_refunded=None,
                   num_placed=None, episode=0):

@@ -13,7 +13,8 @@ from skyjo_rl_amd.vec_env import Obs
 class OracleEngine:
     def __init__(self, num_envs, num_players=3, score_penalty=2.0, observe_other_player_indirect=True,
                  mean_reward=1.0, reward_refunded=0.001, rng_mode=so.RNG_MT19937, auto_reset=True, game_id0=0,
-                 **_):
+                 no_bank=False, **_):
+        self.no_bank = bool(no_bank)  # (the oracle never deals ahead: its stream is numpy's as it stands)
         self.v = so.OracleVec(num_envs=num_envs, num_players=num_players, score_penalty=score_penalty,
                               observe_other_player_indirect=observe_other_player_indirect, mean_reward=mean_reward,
                               reward_refunded=reward_refunded, rng_mode=rng_mode, auto_reset=auto_reset,
@@ -55,6 +56,19 @@ class OracleEngine:
         N = self.num_players
         sc = np.array([[self.v.game(i).final_score[p] for p in range(N)] for i in range(self.num_envs)])
         return self.v.rewards, sc, self.v.dones
+
+    def close(self):
+        pass
+
+    def rng_set(self, game, key, pos):
+        r = self.v.game(game).rng
+        for k, w in enumerate(np.asarray(key, dtype=np.uint32).tolist()):
+            r.mt[k] = w
+        r.idx = int(pos)
+
+    def rng_get(self, game):
+        r = self.v.game(game).rng
+        return np.array(list(r.mt), dtype=np.uint32), int(r.idx)
 
     def rollout_host(self, iters, policy_seed=0):
         self.v.rollout(iters, policy_seed)

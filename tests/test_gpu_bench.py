@@ -1,0 +1,60 @@
+"""GPU: bench.py end to end, as the driver starts it - the one-rank line with every BASELINE configuration in
+`other_configs`, and the multi-rank launch path (`--gpus 2`: bench.py spawns its own torchrun child; on this one-GPU box
+the two ranks share the card, which bench.py only does when told so - otherwise it refuses loudly)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, env=None, timeout=900):
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=e, capture_output=True, text=True, timeout=timeout,
+                          cwd=ROOT)
+
+
+def _line(out):
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_line_carries_every_baseline_config():
+    d = _line(_bench("--steps", "4", "--warmup", "2", "--blocks", "3", "--no-cpu-baseline"))
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["unit"] == "env-steps/s" and d["value"] > 1e9
+    assert d["blocks"]["n"] == 3 and d["blocks"]["min"] <= d["value"] <= d["blocks"]["max"]
+    assert abs(d["value"] - d["blocks"]["median"]) < 1e-6 * d["value"]
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["waits"] == 0
+    assert (d["roofline"]["traffic"] is None) == (d["roofline"]["traffic_source"] is None)
+    oc = d["other_configs"]
+    for k in ("cfg2_4096x2", "cfg4_shard_32768x3", "cfg5_65536x4_model_fp32", "cfg5_65536x4_model_bf16", "philox_65536x3",
+              "direct_obs_65536x3"):
+        assert "error" not in oc[k], (k, oc[k])
+        assert oc[k]["value"] > 1e8 and oc[k]["dominant_kernel_ms"] > 0 and 0 < oc[k]["roofline_frac"] < 1, (k, oc[k])
+    assert oc["cfg5_65536x4_model_fp32"]["illegal"] == 0
+    assert d["speedup_vs_reference_constant"]["vs_1_core"] > 1e5
+
+
+def test_bench_two_ranks_on_one_card_rehearsal_and_refusal():
+    """`bench.py --gpus 2` starts its two ranks itself.  With one GPU visible it must refuse (exit code 3, a message) unless
+    SKYJO_BENCH_SHARED_GPU=1 asks for the rehearsal, in which the ranks share the card and gloo carries the record."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one GPU visible: the refusal / rehearsal paths are for one-GPU boxes")
+    out = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--blocks", "1", "--no-cpu-baseline")
+    assert out.returncode != 0 and "refusing to let ranks share a card" in out.stderr
+    d = _line(_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--blocks", "2", "--no-cpu-baseline", env={"SKYJO_BENCH_SHARED_GPU": "1"}))
+    assert d["n_gpus"] == 2 and d["config"]["shared_gpu_rehearsal"] is True and d["episode_stats"]["ranks"] == 2
+    assert d["config"]["games_per_gpu"] == 65536 and d["value"] > 1e9 and "other_configs" not in d
+    # the two shards together applied steps for 2 x 65 536 games: more than one shard could in the same iterations
+    assert d["episodes"] > 2 * 65536
+    # --config 4: 32 768 games per rank (BASELINE configs[3])
+    d4 = _line(_bench("--gpus", "2", "--config", "4", "--steps", "3", "--warmup", "1", "--blocks", "1", "--no-cpu-baseline",
+                      env={"SKYJO_BENCH_SHARED_GPU": "1"}))
+    assert d4["config"]["games_per_gpu"] == 32768 and d4["config"]["baseline_config"] == 4 and "262 144" in d4["config"]["parallelism"]

@@ -11,11 +11,23 @@ from tests import view_checks as vc
 from tests.oracle_engine import OracleEngine
 
 ENVS = sorted(glob.glob(os.path.join(vc.GOLDEN, "env_*.npz")))
+GLOBAL_CORE = sorted(glob.glob(os.path.join(vc.GOLDEN, "global_core_*.npz")))
+GLOBAL_ENV = sorted(glob.glob(os.path.join(vc.GOLDEN, "global_env_*.npz")))
 
 
 @pytest.mark.parametrize("path", ENVS, ids=[os.path.basename(p)[:-4] for p in ENVS])
 def test_env_golden(path):
     vc.check_env_golden(OracleEngine, path)
+
+
+@pytest.mark.parametrize("path", GLOBAL_CORE, ids=[os.path.basename(p)[:-4] for p in GLOBAL_CORE])
+def test_global_rng_core_loop(path):
+    vc.check_global_core(OracleEngine, path)
+
+
+@pytest.mark.parametrize("path", GLOBAL_ENV, ids=[os.path.basename(p)[:-4] for p in GLOBAL_ENV])
+def test_global_rng_env_loop(path):
+    vc.check_global_env(OracleEngine, path)
 
 
 def test_reproducibility_like_reference():

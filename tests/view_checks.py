@@ -235,3 +235,80 @@ def check_render_golden(engine_factory):
         if hasattr(eng, "close"):
             eng.close()
     return checked
+
+
+def check_global_core(engine_factory, path):
+    """The reference's sample_run loop (rlskyjo/game/sample_game.py:5-28) on numpy's PROCESS-GLOBAL stream -
+    np.random.seed(s); SkyjoGame(...) (deals in its constructor); reset() per game; policy_ra(obs, mask) WITHOUT a generator
+    (random_admissible_policy.py:22-23) - against tests/golden/global_core_*.npz recorded from the reference: every
+    observation, mask, action (the policy's draw comes out of the shared stream, so it pins the stream's position after
+    every deal and reshuffle) and the stream's state (key and pos of np.random.get_state()) at every episode end."""
+    d = np.load(path)
+    N, ind = int(d["num_players"]), bool(d["indirect"])
+    saved = np.random.get_state()
+    try:
+        np.random.seed(int(d["np_seed"]))
+        eng = engine_factory(1, num_players=N, score_penalty=float(d["score_penalty"]), observe_other_player_indirect=ind,
+                             auto_reset=False, no_bank=True)
+        g = SkyjoGame(num_players=N, score_penalty=float(d["score_penalty"]), observe_other_player_indirect=ind, engine=eng,
+                      global_rng=True)
+        row = 0
+        for ep in range(len(d["ep_start"]) - 1):
+            g.reset()
+            np.testing.assert_array_equal(g.players_cards, d["deal_cards"][ep], err_msg=f"deal of episode {ep}")
+            while not g.is_terminated:
+                pid, phase = g.expected_action
+                obs, mask = g.collect_observation(pid)
+                assert (pid, 0 if phase == "draw" else 1) == (d["player"][row], d["phase"][row]), row
+                np.testing.assert_array_equal(obs, d["obs"][row], err_msg=f"row {row}")
+                np.testing.assert_array_equal(mask, d["mask"][row], err_msg=f"row {row}")
+                assert len(g.drawpile) == d["n_draw"][row], row
+                a = int(policy_ra(obs, mask))
+                assert a == d["action"][row], (row, a, d["action"][row])
+                assert int(bool(g.act(pid, a))) == d["over"][row], row
+                row += 1
+            assert row == d["ep_start"][ep + 1]
+            np.testing.assert_array_equal(np.asarray(g.game_metrics["final_score"], dtype=np.float64), d["final_score"][ep])
+            st = np.random.get_state(legacy=True)
+            assert int(st[2]) == d["end_pos"][ep], (ep, st[2], d["end_pos"][ep])
+            np.testing.assert_array_equal(np.asarray(st[1], dtype=np.uint32), d["end_key"][ep], err_msg=f"stream after episode {ep}")
+        return eng
+    finally:
+        np.random.set_state(saved)
+
+
+def check_global_env(engine_factory, path):
+    """The reference's simple_episode loop (rlskyjo/environment/vanilla_env_example.py:6-41) on numpy's process-global
+    stream against tests/golden/global_env_*.npz (pettingzoo stand-ins underneath: wrapper semantics unpinned)."""
+    d = np.load(path)
+    cfg = dict(num_players=int(d["num_players"]), score_penalty=float(d["score_penalty"]),
+               observe_other_player_indirect=bool(d["indirect"]), mean_reward=float(d["mean_reward"]),
+               reward_refunded=float(d["reward_refunded"]))
+    saved = np.random.get_state()
+    try:
+        np.random.seed(int(d["np_seed"]))
+        eng = engine_factory(1, auto_reset=False, no_bank=True, **cfg)
+        e = aec_env.SimpleSkyjoEnv(engine=eng, wrapped=True, global_rng=True, **cfg)
+        row = 0
+        for ep in range(len(d["ep_start"]) - 1):
+            e.reset()
+            for agent in e.agent_iter(max_iter=300 * cfg["num_players"]):
+                obs, reward, done, info = e.last()
+                assert int(agent.split("_")[-1]) == d["agent"][row] and int(done) == d["done"][row], row
+                assert float(reward) == d["cum_reward"][row], (row, reward, d["cum_reward"][row])
+                np.testing.assert_array_equal(obs["observations"], d["obs"][row], err_msg=f"row {row}")
+                np.testing.assert_array_equal(obs["action_mask"], d["mask"][row], err_msg=f"row {row}")
+                if not done:
+                    a = int(policy_ra(obs["observations"], obs["action_mask"]))
+                    assert a == d["action"][row], row
+                    e.step(a)
+                else:
+                    e.step(None)
+                row += 1
+            assert row == d["ep_start"][ep + 1]
+            st = np.random.get_state(legacy=True)
+            assert int(st[2]) == d["end_pos"][ep]
+            np.testing.assert_array_equal(np.asarray(st[1], dtype=np.uint32), d["end_key"][ep])
+        return eng
+    finally:
+        np.random.set_state(saved)
