@@ -356,8 +356,9 @@ int fetch_record(skyjo_vec *h, const uint4 *base, int game, std::vector<uint8_t>
 
 // One launch of the policy net (nets == 2: policy and value branch over the same records, grid.y = 2) in the net's precision.
 // `prof`: the engine whose kernel timing (skyjo_vec_profile, slot 4) collects this launch, or null.
-int launch_mlp(const SkMlpDev &a, const SkMlpDev &b, int nets, const uint8_t *rec, int rec_bytes, int obs_dim, int64_t n, float *out_a,
+int launch_mlp(const skyjo_vec_mlp *ma, const skyjo_vec_mlp *mb, int nets, const uint8_t *rec, int rec_bytes, int obs_dim, int64_t n, float *out_a,
                const SkMlpDraw &draw, float *out_b, hipStream_t s, skyjo_vec *prof = nullptr) {
+  const SkMlpDev &a = ma->net, &b = mb->net;
   const dim3 grid((unsigned)((n + 32 * SKP_GT * SKP_WG - 1) / (32 * SKP_GT * SKP_WG)), (unsigned)nets), block(64 * SKP_WG);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof) {
@@ -420,9 +421,13 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   // aliases this area) + per-lane per-seat float64 statistics
   h->lds_bytes = h->lds_tile + (size_t)SK_TILE * (P.L.indirect ? 64 : P.L.rec_bytes + 16) + (size_t)SK_ACC_KINDS * cfg->num_players * 512 +
                  (cfg->num_players < 8 ? (size_t)cfg->num_players * 1024 : 0);  // + the card chunks of games waiting to be scored
+#ifdef SK_NO_REGACC
+  h->lds_rollout = h->lds_bytes;
+#else
   h->lds_rollout = (cfg->num_players >= 2 && cfg->num_players <= 4)
                        ? h->lds_tile + (size_t)SK_TILE * (P.L.indirect ? 64 : P.L.rec_bytes + 16) + (size_t)cfg->num_players * 1024
                        : h->lds_bytes;
+#endif
   if (const char *e = getenv("SKYJO_LDS_PAD")) h->lds_bytes += (size_t)atoi(e), h->lds_rollout += (size_t)atoi(e);  // diagnostic: caps the wavefronts per CU
   const size_t rec16 = (size_t)P.tiles * P.L.chunks * SK_TILE;
   if ((uint64_t)SK_BANK * rec16 * 16 >= (1ull << 32)) {  // (LDS-DMA addresses the bank with 32-bit offsets)
@@ -757,7 +762,7 @@ int skyjo_vec_model_rollout(skyjo_vec *h, const skyjo_vec_mlp *policy, const sky
     SkMlpDraw d{};
     d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = first_ticket + (uint64_t)t;
     d.game_id0 = h->P.game_id0, d.actions = b->actions + (size_t)t * B, d.logp = b->logp ? b->logp + (size_t)t * B : nullptr;
-    if ((rc = launch_mlp(policy->net, value ? value->net : policy->net, value ? 2 : 1, rec + (size_t)t * B * rb, (int)rb, policy->obs_dim,
+    if ((rc = launch_mlp(policy, value ? value : policy, value ? 2 : 1, rec + (size_t)t * B * rb, (int)rb, policy->obs_dim,
                          (int64_t)B, nullptr, d, value ? b->values + (size_t)t * B * vd : nullptr, s, h)))
       return rc;
     if ((rc = step_once(h, b->actions + (size_t)t * B, rec + (size_t)(t + 1) * B * rb,
@@ -766,7 +771,7 @@ int skyjo_vec_model_rollout(skyjo_vec *h, const skyjo_vec_mlp *policy, const sky
   }
   if (value) {  // the bootstrap value of the records the rollout ends on
     SkMlpDraw nodraw{};
-    if ((rc = launch_mlp(value->net, value->net, 1, rec + (size_t)T * B * rb, (int)rb, value->obs_dim, (int64_t)B, b->values + (size_t)T * B * vd, nodraw,
+    if ((rc = launch_mlp(value, value, 1, rec + (size_t)T * B * rb, (int)rb, value->obs_dim, (int64_t)B, b->values + (size_t)T * B * vd, nodraw,
                          nullptr, s)))
       return rc;
   }
@@ -949,7 +954,7 @@ int skyjo_vec_mlp_forward(const skyjo_vec_mlp *m, const void *records, int32_t r
   if (n == 0) return SKYJO_OK;
   DevGuard guard_(m->device_id);
   SkMlpDraw nodraw{};
-  return launch_mlp(m->net, m->net, 1, (const uint8_t *)records, (int)record_bytes, m->obs_dim, n, out, nodraw, nullptr, (hipStream_t)stream);
+  return launch_mlp(m, m, 1, (const uint8_t *)records, (int)record_bytes, m->obs_dim, n, out, nodraw, nullptr, (hipStream_t)stream);
   return SKYJO_OK;
 }
 
@@ -962,7 +967,7 @@ int skyjo_vec_mlp_act(skyjo_vec *h, const skyjo_vec_mlp *m, const void *records,
   SkMlpDraw d{};
   d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = ticket;
   d.game_id0 = h->P.game_id0, d.actions = actions_out, d.logp = logp_out;
-  return launch_mlp(m->net, m->net, 1, (const uint8_t *)records, (int)h->P.L.rec_bytes, m->obs_dim, n, logits_out, d, nullptr, (hipStream_t)stream);
+  return launch_mlp(m, m, 1, (const uint8_t *)records, (int)h->P.L.rec_bytes, m->obs_dim, n, logits_out, d, nullptr, (hipStream_t)stream);
 }
 
 int skyjo_vec_mlp_act_value(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, const void *records, int64_t n,
@@ -979,7 +984,7 @@ int skyjo_vec_mlp_act_value(skyjo_vec *h, const skyjo_vec_mlp *policy, const sky
   SkMlpDraw d{};
   d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = ticket;
   d.game_id0 = h->P.game_id0, d.actions = actions_out, d.logp = logp_out;
-  return launch_mlp(policy->net, value->net, 2, (const uint8_t *)records, (int)h->P.L.rec_bytes, policy->obs_dim, n, logits_out, d, values_out,
+  return launch_mlp(policy, value, 2, (const uint8_t *)records, (int)h->P.L.rec_bytes, policy->obs_dim, n, logits_out, d, values_out,
                     (hipStream_t)stream);
 }
 

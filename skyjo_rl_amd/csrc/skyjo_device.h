@@ -753,6 +753,23 @@ __device__ __forceinline__ int policy_pick(int phase, const ObsRegs &o, uint32_t
   return pos;
 }
 
+// (the step kernel's register copy of a game's bank bookkeeping: see spare_issue / spare_commit below)
+struct BankRegs {
+  uint32_t ready = 0;  // bit k: slot k holds a ready episode
+  uint32_t dc = 0;     // deals consumed
+  int head = 0;        // slot that is taken next
+};
+__device__ __forceinline__ void bank_read(const SkParams &P, int g, BankRegs &b) {
+  const size_t G = (size_t)P.tiles * SK_TILE;
+  uint8_t r[SK_BANK];
+#pragma unroll
+  for (int k = 0; k < SK_BANK; k++) r[k] = P.spare_ready[(size_t)k * G + g];
+  b.dc = P.deals_consumed[g];
+  b.ready = 0;
+#pragma unroll
+  for (int k = 0; k < SK_BANK; k++) b.ready |= r[k] ? 1u << k : 0u;
+}
+
 // ------------------------------------------------------------------------------------------
 // SkyjoGame.act (skyjo.py:308-335) for the expected player, preceded by the legality test of
 // TerminateIllegalWrapper (skyjo_env.py:23) on the action mask of skyjo.py:201-224.
@@ -766,7 +783,8 @@ __device__ __forceinline__ int policy_pick(int phase, const ObsRegs &o, uint32_t
 template <bool INDIRECT, int NP, bool TRUSTED>
 __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uint8_t *fp, uint8_t *ap, HdrRegs &h, uint32_t v0,
                                              uint32_t v1, uint32_t v2, int a, int g, LaneCounters &cnt, Stamps &st,
-                                             uint8_t *pendp, int &pend_fin, const uint4 &row_pre, double *racc = nullptr) {
+                                             uint8_t *pendp, int &pend_fin, const uint4 &row_pre, double *racc = nullptr,
+                                             BankRegs *bank = nullptr) {
   const int N = P.L.N;
   const int phase = h.w0 & 0xff, p = (h.w0 >> 8) & 0xff;
   const int blk = sk_pb(P.L, p), cardb = blk + PB_CARDS, visb = blk + PB_VIS, pb = P.L.off_pile;
@@ -852,6 +870,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
       }
 #endif
       HDR_LOAD(h);
+      if (bank) bank_read(P, g, *bank);  // (in MT19937 mode the reshuffle took the pre-dealt episodes back)
       cnt.reshuffles++;
       nd = h.w1 & 0xff;
       pile_top = LI(pb + pile_addr((h.w1 >> 16) & 1, nd - 1));
@@ -1041,36 +1060,34 @@ __device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, in
   return true;
 }
 
-// The step kernel's form, in two halves.  `spare_issue` asks for the whole record by LDS-DMA straight into the lane's
-// own (dead: its game is over) slot of the tile - no registers, no LDS writes - and for the two words of bookkeeping;
-// `spare_commit` waits for everything this wavefront has in flight and finishes the hand-over.  Between the two the
-// wavefront steps its live games, which hides the memory round trip of the few lanes that are resetting (about every
-// second iteration has one).  If the bank turns out to be empty the slot holds a stale record: the caller deals in
-// place, which rewrites every word of it.
-struct SpareRegs {
-  uint32_t dc;
-  int head;
-  uint8_t ready;
-};
-__device__ __forceinline__ void spare_issue(const SkParams &P, uint8_t *lp, uint32_t lds_tile, int tile, int lane, int g, SpareRegs &r) {
-  const size_t G = (size_t)P.tiles * SK_TILE;
-  r.head = LB(H_BANK) % SK_BANK;  // (read before the record is overwritten)
-  r.ready = P.spare_ready[(size_t)r.head * G + g];
-  r.dc = P.deals_consumed[g];
-  const uint32_t voff = (uint32_t)((((size_t)r.head * P.tiles + tile) * P.L.chunks * SK_TILE + lane) * 16);
+// The step kernel's form.  What a game's bank looks like - which slots hold a ready episode, which slot is taken next, how
+// many deals the game has consumed - only changes between launches (dealing runs, the publish at the top of a launch) or by
+// this very lane (it consumes an episode; a rare path rolls the bank back), so the lane keeps it in REGISTERS for the whole
+// launch (BankRegs): the hand-over of a finished game needs no global load, and therefore no wait for one.
+//   `spare_issue`   at the top of the reset iteration: asks for the whole record of slot `head` by LDS-DMA straight into the
+//                   lane's own (dead: its game is over) slot of the tile - no registers, no LDS writes;
+//   `spare_commit`  waits for what this wavefront has in flight and finishes the hand-over (fire-and-forget stores).
+// Between the two the wavefront steps its live games, which hides the memory round trip of the few lanes that are
+// resetting (about every second iteration has one).  (Requested a whole iteration earlier - at the end of the iteration in
+// which the game ends - the record is no earlier where it counts: k_step 119.5 -> 127.4 us in line, and beside a dealing
+// kernel on a full chip 192 us either way: EXPERIMENTS.md.)  A bank without a ready episode: the caller deals in place
+// (deal_inline) and re-reads the bank.
+__device__ __forceinline__ bool bank_has(const BankRegs &b) { return ((b.ready >> b.head) & 1u) != 0; }
+__device__ __forceinline__ void spare_issue(const SkParams &P, uint32_t lds_tile, int tile, int lane, const BankRegs &b) {
+  const uint32_t voff = (uint32_t)((((size_t)b.head * P.tiles + tile) * P.L.chunks * SK_TILE + lane) * 16);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the old record has returned
 #ifndef SK_EXP_NO_DMA
   dma_record<false>((const uint8_t *)P.spare, voff, lds_tile, P.L.chunks);
 #endif
 }
-__device__ __forceinline__ bool spare_commit(const SkParams &P, uint8_t *lp, int g, const SpareRegs &r) {
+__device__ __forceinline__ void spare_commit(const SkParams &P, uint8_t *lp, int g, BankRegs &b) {
 #ifndef SK_EXP_NO_DRAIN
   sk_vm_drain();
 #endif
-  if (!r.ready) return false;
-  P.spare_ready[(size_t)r.head * (size_t)P.tiles * SK_TILE + g] = 0;  // k_scan finds the banks that are not full
-  bank_advance(P, lp, g, r.head, r.dc);
-  return true;
+  P.spare_ready[(size_t)b.head * (size_t)P.tiles * SK_TILE + g] = 0;  // the dealing run finds the banks that are not full
+  bank_advance(P, lp, g, b.head, b.dc);
+  b.ready &= ~(1u << b.head);
+  b.head = (b.head + 1) % SK_BANK, b.dc++;
 }
 
 // LDS stride of one staged record: the record's own size, plus 16 bytes when that is a multiple of 32 dwords / 4 - the
@@ -1185,7 +1202,11 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   // keep the per-seat statistics in registers (REGACC) - their LDS is tile | staging | card chunks, nothing else: at three
   // players 25 KB per wavefront, so that four dealing wavefronts (14.75 KB each) fit beside a CU's four step wavefronts.
   constexpr bool DEFER = POLICY && NP > 0 && NP < 8;
+#ifdef SK_NO_REGACC
+  constexpr bool REGACC = false;
+#else
   constexpr bool REGACC = DEFER;
+#endif
   constexpr int NACC = REGACC ? SK_ACC_KINDS * NP : 1;
   double racc_store[NACC];
 #pragma unroll
@@ -1212,6 +1233,11 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   const uint64_t gid = P.game_id0 + (uint64_t)g;
   ObsRegs ob;
   if (valid) obs_load(P, lp, (h.w0 >> 8) & 0xff, ob);
+  BankRegs bank;
+  if (valid && P.auto_reset) {
+    bank_read(P, g, bank);
+    bank.head = LB(H_BANK) % SK_BANK;
+  }
   for (int it = 0; it < iters; it++) {
     const uint64_t iter = iter0 + (uint64_t)it;
     if (POLICY && (it == 0 || (iter & 3) == 0)) {
@@ -1232,10 +1258,10 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
       if (!POLICY) a = actions[g];
       const bool skip = !POLICY && a == SKYJO_ACTION_SKIP;
       const bool acted = !over && !skip;  // this iteration applies (or refuses) an action of this game
-      SpareRegs sp;
       const bool frozen = (h.w0 >> 24) == SKYJO_ST_ERROR;  // (device error: stays as it is until the handle is re-seeded)
       const bool resetting = over && P.auto_reset && !skip && !frozen;
-      if (resetting) spare_issue(P, lp, lds_tile, tile, lane, g, sp);  // lands while the live games step
+      const bool from_bank = resetting && bank_has(bank);
+      if (from_bank) spare_issue(P, lds_tile, tile, lane, bank);  // lands while the live games step
       if (!over && !skip) {
         const uint32_t v0 = ob.q0, v1 = ob.q1, v2 = ob.q2;  // the acting player's row, read for the previous record
         STAMP(2);
@@ -1250,7 +1276,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
 #ifndef SK_STAMPS_FINE
         STAMP(3);
 #endif
-        apply_action<INDIRECT, NP, POLICY>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st, pendp, pend_fin, row_pre, racc);
+        apply_action<INDIRECT, NP, POLICY>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st, pendp, pend_fin, row_pre, racc, &bank);
 #ifdef SK_STAMPS_FINE
         STAMP(6);
 #else
@@ -1260,9 +1286,12 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
         a = -1;
         if (resetting) {
           bool dealt = true;
-          if (!spare_commit(P, lp, g, sp)) {
+          if (SK_OFTEN(from_bank)) {
+            spare_commit(P, lp, g, bank);
+          } else {
 #ifndef SK_EXP_NO_RARE
-            dealt = deal_inline(P, lp, fp, g, tile, lane, sp.head);
+            dealt = deal_inline(P, lp, fp, g, tile, lane, bank.head);
+            bank_read(P, g, bank);
 #endif
             cnt.waits++;  // counts the slow-path deals
           }
