@@ -52,7 +52,7 @@ extern "C" {
 #define SKYJO_ST_ILLEGAL 1   /* action masked out or out of range: TerminateIllegalWrapper semantics */
 #define SKYJO_ST_NOOP_DONE 2 /* game already over and auto_reset off (skyjo.py:316-321) */
 #define SKYJO_ST_RESET 3     /* game was over: a new episode was dealt, the action was ignored */
-#define SKYJO_ST_ERROR 4     /* the engine raised a device error (skyjo_vec_check_error): the game is frozen until re-seeded */
+#define SKYJO_ST_ERROR 4     /* the engine raised a device error (skyjo_vec_check_error): this episode was cut off / could not be dealt */
 
 /* skyjo_vec_step: a game whose action is SKYJO_ACTION_SKIP is left exactly as it is (no step, no reset; its record is
  * still written) - the single-game views use it to step ONE game of a shared engine (SkyjoGame(engine=, index=)). */
@@ -182,7 +182,8 @@ const uint8_t *skyjo_vec_done_ptr(const skyjo_vec *h);
 
 /* Sticky device error of the handle: 0, or SKYJO_E_DEVICE with the reason in skyjo_vec_last_error() - today the one case
  * is a step kernel that gave up waiting for the dealing kernel that should run beside it (SKYJO_OPT_OVERLAP); the games
- * concerned are frozen (SKYJO_ST_ERROR), results since then are void, skyjo_vec_seed clears it.  Synchronises `stream`.
+ * concerned show SKYJO_ST_ERROR once (the stream the dealing kernel may still hold is left alone), results since then
+ * are void, skyjo_vec_seed clears it.  Synchronises `stream`.
  * Every synchronising call below (and the *_host conveniences, snapshot_create) makes the same check by itself. */
 int skyjo_vec_check_error(skyjo_vec *h, void *stream);
 

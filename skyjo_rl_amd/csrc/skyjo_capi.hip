@@ -145,13 +145,22 @@ struct skyjo_vec_snapshot {
 
 namespace {
 
-// The sticky device error (skyjo_device.h: SK_ERR_*), as the kernels left it in the host-mapped word: valid after any
-// synchronisation with the stream the kernels ran on.
+// The sticky device error (skyjo_device.h: SK_ERR_*) as the host-style kernels (step with caller actions, reset, observe)
+// left it in the host-mapped word: valid after any synchronisation with the stream they ran on.  The fused rollout kernel does
+// not write that word: dev_error_fetch() reads the device's own copy first (get_counters, check_error, snapshot_create).
 int dev_error_check(const skyjo_vec *h) {
   if (h->health_host && (h->health_host[2] & SK_ERR_DEAL_TIMEOUT))
     return fail(SKYJO_E_DEVICE, "a step kernel gave up waiting for the dealing kernel that should run beside it (SKYJO_OPT_OVERLAP): "
                                 "results since then are void; switch the option off or re-seed");
   return SKYJO_OK;
+}
+
+int dev_error_fetch(skyjo_vec *h, hipStream_t s) {
+  uint32_t err = 0;
+  HIPCHK(hipMemcpyAsync(&err, h->P.dev_error, sizeof(err), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  h->health_host[2] |= err;
+  return dev_error_check(h);
 }
 
 template <class T>
@@ -618,7 +627,7 @@ int skyjo_vec_snapshot_create(skyjo_vec *h, skyjo_vec_snapshot **out, void *stre
   int rc;
   if ((rc = publish_deals(h, s))) return rc;  // no deal in flight: the arrays below are the whole truth
   HIPCHK(hipDeviceSynchronize());
-  if ((rc = dev_error_check(h))) return rc;   // (a voided run is not worth keeping)
+  if ((rc = dev_error_fetch(h, s))) return rc;   // (a voided run is not worth keeping)
   skyjo_vec_snapshot *sn = new (std::nothrow) skyjo_vec_snapshot();
   if (!sn) return fail(SKYJO_E_INVALID, "out of host memory");
   sn->owner = h, sn->owner_generation = h->generation, sn->device_id = h->cfg.device_id;
@@ -1008,14 +1017,13 @@ int skyjo_vec_get_counters(skyjo_vec *h, skyjo_vec_counters *out, void *stream) 
   HIPCHK(hipMemcpyAsync(out, h->P.counters, sizeof(SkCounters), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   out->iters = h->iters_total;
-  return dev_error_check(h);
+  return dev_error_fetch(h, s);
 }
 
 int skyjo_vec_check_error(skyjo_vec *h, void *stream) {
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
   GUARD(h);
-  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-  return dev_error_check(h);
+  return dev_error_fetch(h, (hipStream_t)stream);
 }
 
 int skyjo_vec_reset_counters(skyjo_vec *h, void *stream) {

@@ -469,23 +469,24 @@ __device__ __forceinline__ void reshuffle_discard(const SkParams &P, uint8_t *lp
 // Returns SK_WAIT_OK when that deal is finished, SK_WAIT_GAVE_UP when it gave itself up (close to a full turn of the generator
 // state, see k_deal: it then left no record and no trace in the stream), SK_WAIT_TIMEOUT when the dealing launch never showed
 // up (it is not resident beside this kernel and this kernel cannot end before it starts).  After a timeout the dealing
-// kernel may still be writing the game's stream: the caller must leave the stream and the bank slot alone and freeze the
-// game (sk_freeze); the sticky error words make every later host call on the handle fail until it is re-seeded.
+// kernel may still be writing the game's stream: the caller must leave the stream and the bank slot alone.  It marks the
+// game done on the spot (this episode is cut off - results are void from here on) and the sticky error word makes every
+// later synchronising host call on the handle fail until it is re-seeded.  (Kept as small as this on purpose: the rare
+// paths are inlined into the step kernel, and what they contain moves the register allocation of its hot loop - an early
+// exit on the sticky word and a host-mapped store in here cost the fused rollout 2 % of its time.)
 #define SK_WAIT_OK 0
 #define SK_WAIT_GAVE_UP 1
 #define SK_WAIT_TIMEOUT 2
 __device__ __forceinline__ int wait_deal_done(const SkParams &P, int g) {
   uint32_t f = 0;
   const uint32_t tag = P.plan_tag[g];  // the run that owns the game's busy slot (written on this stream, before this kernel or by this lane)
-  if (__hip_atomic_load(P.dev_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & SK_ERR_DEAL_TIMEOUT) return SK_WAIT_TIMEOUT;  // (already given up: do not spin again)
   for (int spin = 0; spin < (1 << P.spin_log2); spin++) {
     f = __hip_atomic_load(&P.done_flag[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((f & 0x7fffffffu) == tag) break;
     __builtin_amdgcn_s_sleep(32);
   }
   if ((f & 0x7fffffffu) != tag) {
-    atomicOr(P.dev_error, SK_ERR_DEAL_TIMEOUT);
-    P.health_host[2] = SK_ERR_DEAL_TIMEOUT;  // (host-mapped: every synchronising host call looks at it)
+    atomicOr(P.dev_error, SK_ERR_DEAL_TIMEOUT);  // (the host-style kernels hand the word to the host: sk_error_to_host)
     return SK_WAIT_TIMEOUT;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -527,8 +528,10 @@ __device__ __forceinline__ int mt_rollback(const SkParams &P, uint32_t *mt, int 
   return snap;
 }
 
-// Returns false - with nothing touched - when the game's stream cannot be had (wait_deal_done timed out).
-__device__ __forceinline__ bool reshuffle_dispatch(const SkParams &P, uint8_t *lp, uint8_t *fp, int g) {
+// When the game's stream cannot be had (wait_deal_done timed out: sticky device error) nothing of it is touched: the game
+// is marked done in its LDS header - status SKYJO_ST_ERROR, one stale card left on the draw pile for the draw that called -
+// and the step kernel carries on without a branch of its own for this.
+__device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *lp, uint8_t *fp, int g) {
   if (P.rng_mode == SKYJO_RNG_MT19937) {
     const size_t G = (size_t)P.tiles * SK_TILE;
     uint32_t *mt = P.mt + (size_t)g * 624;
@@ -540,7 +543,11 @@ __device__ __forceinline__ bool reshuffle_dispatch(const SkParams &P, uint8_t *l
     bool undo_inflight = false;
     if (inflight) {  // a deal is in flight for this game: let it finish, then undo it as well
       const int w = wait_deal_done(P, g);
-      if (w == SK_WAIT_TIMEOUT) return false;
+      if (w == SK_WAIT_TIMEOUT) {
+        LB(H_FLAGS) |= F_DONE, LB(H_STATUS) = SKYJO_ST_ERROR, LB(H_NDRAW) = 1;
+        P.done[g] = 1;
+        return;
+      }
       undo_inflight = w == SK_WAIT_OK;
       P.cancel[g] = 1;
     }
@@ -562,7 +569,6 @@ __device__ __forceinline__ bool reshuffle_dispatch(const SkParams &P, uint8_t *l
     r.open(P.seeds[g] + 1, *(uint32_t *)(lp + LIDX(H_EPISODE)), LB(H_RESH), 1u);
     reshuffle_discard(P, lp, r);
   }
-  return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -753,23 +759,6 @@ __device__ __forceinline__ int policy_pick(int phase, const ObsRegs &o, uint32_t
   return pos;
 }
 
-// (the step kernel's register copy of a game's bank bookkeeping: see spare_issue / spare_commit below)
-struct BankRegs {
-  uint32_t ready = 0;  // bit k: slot k holds a ready episode
-  uint32_t dc = 0;     // deals consumed
-  int head = 0;        // slot that is taken next
-};
-__device__ __forceinline__ void bank_read(const SkParams &P, int g, BankRegs &b) {
-  const size_t G = (size_t)P.tiles * SK_TILE;
-  uint8_t r[SK_BANK];
-#pragma unroll
-  for (int k = 0; k < SK_BANK; k++) r[k] = P.spare_ready[(size_t)k * G + g];
-  b.dc = P.deals_consumed[g];
-  b.ready = 0;
-#pragma unroll
-  for (int k = 0; k < SK_BANK; k++) b.ready |= r[k] ? 1u << k : 0u;
-}
-
 // ------------------------------------------------------------------------------------------
 // SkyjoGame.act (skyjo.py:308-335) for the expected player, preceded by the legality test of
 // TerminateIllegalWrapper (skyjo_env.py:23) on the action mask of skyjo.py:201-224.
@@ -783,8 +772,7 @@ __device__ __forceinline__ void bank_read(const SkParams &P, int g, BankRegs &b)
 template <bool INDIRECT, int NP, bool TRUSTED>
 __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uint8_t *fp, uint8_t *ap, HdrRegs &h, uint32_t v0,
                                              uint32_t v1, uint32_t v2, int a, int g, LaneCounters &cnt, Stamps &st,
-                                             uint8_t *pendp, int &pend_fin, const uint4 &row_pre, double *racc = nullptr,
-                                             BankRegs *bank = nullptr) {
+                                             uint8_t *pendp, int &pend_fin, const uint4 &row_pre, double *racc = nullptr) {
   const int N = P.L.N;
   const int phase = h.w0 & 0xff, p = (h.w0 >> 8) & 0xff;
   const int blk = sk_pb(P.L, p), cardb = blk + PB_CARDS, visb = blk + PB_VIS, pb = P.L.off_pile;
@@ -863,14 +851,9 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
     if (from_pile && nd == 0) {  // rare: works on the LDS copy of the header
       HDR_FLUSH(h);
 #ifndef SK_EXP_NO_RARE
-      if (SK_RARE(!reshuffle_dispatch(P, lp, fp, g))) {  // device error (sticky): the game is frozen, nothing was drawn
-        h.w0 = (h.w0 & 0x0000ffffu) | ((((h.w0 >> 16) & 0xffu) | F_DONE) << 16) | ((uint32_t)SKYJO_ST_ERROR << 24);
-        P.done[g] = 1;
-        return;
-      }
+      reshuffle_dispatch(P, lp, fp, g);
 #endif
       HDR_LOAD(h);
-      if (bank) bank_read(P, g, *bank);  // (in MT19937 mode the reshuffle took the pre-dealt episodes back)
       cnt.reshuffles++;
       nd = h.w1 & 0xff;
       pile_top = LI(pb + pile_addr((h.w1 >> 16) & 1, nd - 1));
@@ -1060,34 +1043,33 @@ __device__ __forceinline__ bool consume_spare(const SkParams &P, uint8_t *lp, in
   return true;
 }
 
-// The step kernel's form.  What a game's bank looks like - which slots hold a ready episode, which slot is taken next, how
-// many deals the game has consumed - only changes between launches (dealing runs, the publish at the top of a launch) or by
-// this very lane (it consumes an episode; a rare path rolls the bank back), so the lane keeps it in REGISTERS for the whole
-// launch (BankRegs): the hand-over of a finished game needs no global load, and therefore no wait for one.
-//   `spare_issue`   at the top of the reset iteration: asks for the whole record of slot `head` by LDS-DMA straight into the
-//                   lane's own (dead: its game is over) slot of the tile - no registers, no LDS writes;
-//   `spare_commit`  waits for what this wavefront has in flight and finishes the hand-over (fire-and-forget stores).
-// Between the two the wavefront steps its live games, which hides the memory round trip of the few lanes that are
-// resetting (about every second iteration has one).  (Requested a whole iteration earlier - at the end of the iteration in
-// which the game ends - the record is no earlier where it counts: k_step 119.5 -> 127.4 us in line, and beside a dealing
-// kernel on a full chip 192 us either way: EXPERIMENTS.md.)  A bank without a ready episode: the caller deals in place
-// (deal_inline) and re-reads the bank.
-__device__ __forceinline__ bool bank_has(const BankRegs &b) { return ((b.ready >> b.head) & 1u) != 0; }
-__device__ __forceinline__ void spare_issue(const SkParams &P, uint32_t lds_tile, int tile, int lane, const BankRegs &b) {
-  const uint32_t voff = (uint32_t)((((size_t)b.head * P.tiles + tile) * P.L.chunks * SK_TILE + lane) * 16);
+// The step kernel's form, in two halves.  `spare_issue` asks for the whole record by LDS-DMA straight into the lane's
+// own (dead: its game is over) slot of the tile - no registers, no LDS writes - and for the two words of bookkeeping;
+// `spare_commit` waits for everything this wavefront has in flight and finishes the hand-over.  Between the two the
+// wavefront steps its live games, which hides the memory round trip of the few lanes that are resetting (about every
+// second iteration has one).  If the bank turns out to be empty the slot holds a stale record: the caller deals in
+// place, which rewrites every word of it.  (Measured and dropped in round 3, EXPERIMENTS.md: the bookkeeping words kept in
+// registers for the whole launch - same time; the record requested a whole iteration earlier, when the game ends - slower.)
+struct SpareRegs {
+  uint32_t dc;
+  int head;
+  uint8_t ready;
+};
+__device__ __forceinline__ void spare_issue(const SkParams &P, uint8_t *lp, uint32_t lds_tile, int tile, int lane, int g, SpareRegs &r) {
+  const size_t G = (size_t)P.tiles * SK_TILE;
+  r.head = LB(H_BANK) % SK_BANK;  // (read before the record is overwritten)
+  r.ready = P.spare_ready[(size_t)r.head * G + g];
+  r.dc = P.deals_consumed[g];
+  const uint32_t voff = (uint32_t)((((size_t)r.head * P.tiles + tile) * P.L.chunks * SK_TILE + lane) * 16);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the old record has returned
-#ifndef SK_EXP_NO_DMA
   dma_record<false>((const uint8_t *)P.spare, voff, lds_tile, P.L.chunks);
-#endif
 }
-__device__ __forceinline__ void spare_commit(const SkParams &P, uint8_t *lp, int g, BankRegs &b) {
-#ifndef SK_EXP_NO_DRAIN
+__device__ __forceinline__ bool spare_commit(const SkParams &P, uint8_t *lp, int g, const SpareRegs &r) {
   sk_vm_drain();
-#endif
-  P.spare_ready[(size_t)b.head * (size_t)P.tiles * SK_TILE + g] = 0;  // the dealing run finds the banks that are not full
-  bank_advance(P, lp, g, b.head, b.dc);
-  b.ready &= ~(1u << b.head);
-  b.head = (b.head + 1) % SK_BANK, b.dc++;
+  if (!r.ready) return false;
+  P.spare_ready[(size_t)r.head * (size_t)P.tiles * SK_TILE + g] = 0;  // the dealing run finds the banks that are not full
+  bank_advance(P, lp, g, r.head, r.dc);
+  return true;
 }
 
 // LDS stride of one staged record: the record's own size, plus 16 bytes when that is a multiple of 32 dwords / 4 - the
@@ -1097,8 +1079,9 @@ __device__ __forceinline__ constexpr int sk_stage_stride(int rec_bytes) { return
 // Fallback when the pre-dealt episode is not available inside a launch (a mid-game reshuffle just
 // invalidated it, or the game already took one in this launch): deal right here, on this lane, from
 // the game's current stream position.  Rare and slow (one lane active), never changes results.
-// Returns false - stream, bank and record untouched - when the game's stream cannot be had (wait_deal_done timed out).
-__device__ __forceinline__ bool deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane, int head);
+// When the game's stream cannot be had (wait_deal_done timed out: sticky device error) stream and bank stay untouched and
+// the slot is left as a finished game: it asks again in the next iteration.
+__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane, int head);
 
 // ------------------------------------------------------------------------------------------
 // k_step: `iters` lockstep iterations over all tiles.  POLICY=false: one iteration with the
@@ -1172,6 +1155,11 @@ __device__ __forceinline__ void sk_plan_deals(const SkParams &P, int g) {
 // packed record as it lies in LDS (chunk c at byte 16 c), then rewards[N], scores[N] (float64), the stream position word
 // and the done byte - into host-mapped memory, so that skyjo_vec_get_state / get_rewards_host after a *_host call cost
 // no device traffic at all (skyjo_capi.hip: raw_valid).
+// The sticky device error (SK_ERR_*) goes to the host-mapped word that every synchronising host call looks at - written
+// by the kernels behind those calls (k_step with caller actions, k_reset, k_observe), not by the fused rollout kernel.
+__device__ __forceinline__ void sk_error_to_host(const SkParams &P) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) P.health_host[2] = *P.dev_error;
+}
 __device__ __forceinline__ void sk_export_raw(const SkParams &P, uint8_t *lp, int g, uint8_t *o) {
   for (int c = 0; c < P.L.chunks; c++) ((uint4 *)o)[c] = LQ(c);
   double *d = (double *)(o + P.L.state_bytes);
@@ -1233,11 +1221,6 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   const uint64_t gid = P.game_id0 + (uint64_t)g;
   ObsRegs ob;
   if (valid) obs_load(P, lp, (h.w0 >> 8) & 0xff, ob);
-  BankRegs bank;
-  if (valid && P.auto_reset) {
-    bank_read(P, g, bank);
-    bank.head = LB(H_BANK) % SK_BANK;
-  }
   for (int it = 0; it < iters; it++) {
     const uint64_t iter = iter0 + (uint64_t)it;
     if (POLICY && (it == 0 || (iter & 3) == 0)) {
@@ -1258,10 +1241,9 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
       if (!POLICY) a = actions[g];
       const bool skip = !POLICY && a == SKYJO_ACTION_SKIP;
       const bool acted = !over && !skip;  // this iteration applies (or refuses) an action of this game
-      const bool frozen = (h.w0 >> 24) == SKYJO_ST_ERROR;  // (device error: stays as it is until the handle is re-seeded)
-      const bool resetting = over && P.auto_reset && !skip && !frozen;
-      const bool from_bank = resetting && bank_has(bank);
-      if (from_bank) spare_issue(P, lds_tile, tile, lane, bank);  // lands while the live games step
+      SpareRegs sp;
+      const bool resetting = over && P.auto_reset && !skip;
+      if (resetting) spare_issue(P, lp, lds_tile, tile, lane, g, sp);  // lands while the live games step
       if (!over && !skip) {
         const uint32_t v0 = ob.q0, v1 = ob.q1, v2 = ob.q2;  // the acting player's row, read for the previous record
         STAMP(2);
@@ -1276,7 +1258,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
 #ifndef SK_STAMPS_FINE
         STAMP(3);
 #endif
-        apply_action<INDIRECT, NP, POLICY>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st, pendp, pend_fin, row_pre, racc, &bank);
+        apply_action<INDIRECT, NP, POLICY>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st, pendp, pend_fin, row_pre, racc);
 #ifdef SK_STAMPS_FINE
         STAMP(6);
 #else
@@ -1284,25 +1266,17 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
 #endif
       } else if (!skip) {
         a = -1;
-        if (resetting) {
-          bool dealt = true;
-          if (SK_OFTEN(from_bank)) {
-            spare_commit(P, lp, g, bank);
-          } else {
+        if (P.auto_reset) {
+          if (!spare_commit(P, lp, g, sp)) {
 #ifndef SK_EXP_NO_RARE
-            dealt = deal_inline(P, lp, fp, g, tile, lane, bank.head);
-            bank_read(P, g, bank);
+            deal_inline(P, lp, fp, g, tile, lane, sp.head);
 #endif
             cnt.waits++;  // counts the slow-path deals
           }
           HDR_LOAD(h);
-          if (SK_OFTEN(dealt)) {
-            h.w0 = (h.w0 & 0x00ffffffu) | ((uint32_t)SKYJO_ST_RESET << 24);
-            cnt.resets++;
-          } else {  // device error (sticky): the slot holds a stale record - frozen as a finished game
-            h.w0 = (h.w0 & 0x0000ffffu) | (((uint32_t)F_VALID | F_DONE) << 16) | ((uint32_t)SKYJO_ST_ERROR << 24);
-          }
-        } else if (!frozen) {
+          h.w0 = (h.w0 & 0x00ffffffu) | ((uint32_t)SKYJO_ST_RESET << 24);
+          cnt.resets++;
+        } else {
           h.w0 = (h.w0 & 0x00ffffffu) | ((uint32_t)SKYJO_ST_NOOP_DONE << 24);
         }
         STAMP(1);
@@ -1428,6 +1402,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   HDR_FLUSH(h);
   tile_store_nt(P, P.state, tile, lane, lp);
   if (!POLICY && raw_out && valid) sk_export_raw(P, lp, g, raw_out + (size_t)g * raw_stride);
+  if (!POLICY) sk_error_to_host(P);
   if (P.ov_flags & 2u) {
     // (first what the run beside THIS launch has dealt: a game whose busy mark outlived the launch in which it is dealt would
     // get a new episode only every second run.  The dealing kernel was started before this launch and is as good as through:
@@ -1482,6 +1457,7 @@ __global__ __launch_bounds__(SK_TILE) void k_observe(SkParams P, const int32_t *
   extern __shared__ uint32_t lds_raw[];
   const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 16;
+  sk_error_to_host(P);
   tile_load(P, P.state, tile, lane, lp);
   if (!(LB(H_FLAGS) & F_VALID)) return;
   HdrRegs h;
@@ -1505,9 +1481,8 @@ __global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *ma
   tile_load(P, P.state, tile, lane, lp);
   if (want) {
     const int head = P.bank_head[g] % SK_BANK;
-    const bool dealt = consume_spare(P, lp, tile, lane, g, head) || deal_inline(P, lp, fp, g, tile, lane, head);
+    if (!consume_spare(P, lp, tile, lane, g, head)) deal_inline(P, lp, fp, g, tile, lane, head);
     LB(H_STATUS) = SKYJO_ST_RESET;
-    if (!dealt) LB(H_FLAGS) |= F_DONE, LB(H_STATUS) = SKYJO_ST_ERROR;  // device error (sticky): frozen as it is
   }
   HdrRegs h;
   HDR_LOAD(h);
@@ -1518,6 +1493,7 @@ __global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *ma
   }
   if (want) tile_store(P, P.state, tile, lane, lp);
   if (raw_out && (LB(H_FLAGS) & F_VALID)) sk_export_raw(P, lp, g, raw_out + (size_t)g * raw_stride);
+  sk_error_to_host(P);
   const unsigned long long wb = __ballot(want);
   if (want && lane == __ffsll((long long)wb) - 1) P.tile_counters[(size_t)tile * 8 + 3] += __popcll(wb);
 }
@@ -2039,7 +2015,7 @@ __device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rn
   refresh_minima(P, lp);
 }
 
-__device__ __forceinline__ bool deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane, int head) {
+__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane, int head) {
   const uint32_t ep = P.deals_consumed[g];
   const int busy = P.busy[g];
   if (busy) {
@@ -2048,12 +2024,15 @@ __device__ __forceinline__ bool deal_inline(const SkParams &P, uint8_t *lp, uint
     const bool cancelled = P.cancel[g] != 0;
     if (P.rng_mode == SKYJO_RNG_MT19937 && !cancelled) {  // the stream is shared: wait for that deal and take it
       const int w = wait_deal_done(P, g);
-      if (w == SK_WAIT_TIMEOUT) return false;
+      if (w == SK_WAIT_TIMEOUT) {
+        LB(H_FLAGS) = F_VALID | F_DONE, LB(H_STATUS) = SKYJO_ST_ERROR;
+        return;
+      }
       P.cancel[g] = 1;  // taken here: the publishing kernel must not mark the slot ready
       if (w == SK_WAIT_OK) {
         load_spare(P, lp, busy - 1, tile, lane);
         bank_advance(P, lp, g, head, ep);
-        return true;
+        return;
       }
     }  // Philox deals do not depend on a stream position (and a cancelled / overrun MT deal has finished): deal here
     P.cancel[g] = 1;  // superseded: the publishing kernel must not mark the slot ready
@@ -2071,7 +2050,6 @@ __device__ __forceinline__ bool deal_inline(const SkParams &P, uint8_t *lp, uint
   LB(H_BANK) = (uint8_t)head;  // the bank is empty; its head pointer survives the new record
   P.deals_consumed[g] = ep + 1;
   P.done[g] = 0;
-  return true;
 }
 
 // ------------------------------------------------------------------------------------------

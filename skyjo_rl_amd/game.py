@@ -88,6 +88,15 @@ class SkyjoGame(object):
                          status=int(obs.status[i]))
         self._state = None
 
+    def _take_row(self, row):
+        """The same from one raw record (include/skyjo_vec.h has the layout): ``SkyjoVecEnv.step_one``'s fast path."""
+        D = self.obs_shape[0]
+        dp = (D + 3) & ~3
+        i8 = row.view(np.int8)
+        self._rec = dict(observations=i8[:D].copy(), action_mask=i8[dp:dp + 26].copy(), agent=int(row[dp + 26]),
+                         phase=int(row[dp + 27]), done=bool(row[dp + 28]), status=int(row[dp + 29]))
+        self._state = None
+
     def _state_now(self):
         if self._state is None:
             self._state = self._engine.get_state(self._i)
@@ -164,13 +173,17 @@ class SkyjoGame(object):
             assert self._rec["action_mask"][action_int] == 1, (
                 f"illegal action {self.render_action_explainer(action_int)}."
                 f"card is already revealed: {self.players_masked[player_id]}")
-        acts = self._only_me(int(action_int), self._engine.ACTION_SKIP, np.int32)  # the other games stay as they are
+        # (the other games of a shared engine stay as they are: ACTION_SKIP)
         # the one step that draws random numbers: taking a card from an EMPTY draw pile reshuffles the discard pile first
         # (skyjo.py:361-365) - with the caller's stream when that is the contract
         lend = self._global_rng and action_int == 24 and self._state_now()["n_draw"] == 0 and self._state_now()["hand"] == 15
         if lend:
             self._stream_to_device()
-        self._take(self._engine.step_host(acts))
+        step_one = getattr(self._engine, "step_one", None)
+        if step_one is not None:
+            self._take_row(step_one(self._i, int(action_int)))
+        else:
+            self._take(self._engine.step_host(self._only_me(int(action_int), self._engine.ACTION_SKIP, np.int32)))
         if lend:
             self._stream_from_device()
         assert self._rec["status"] != ST_ILLEGAL

@@ -229,6 +229,21 @@ class SkyjoVecEnv:
         _lib.check(self._L.skyjo_vec_step_host(self._h, a.ctypes.data_as(C.c_void_p), rec.ctypes.data_as(C.c_void_p)))
         return split_records_np(rec, self.obs_dim)
 
+    def step_one(self, game, action):
+        """Host-style step of ONE game (every other game gets ACTION_SKIP) with nothing allocated per call: the single-game
+        views' fast path.  Returns that game's record as a uint8 row (a view that the next ``step_one`` overwrites)."""
+        one = getattr(self, "_one", None)
+        if one is None:
+            acts = np.full(self.num_envs, self.ACTION_SKIP, dtype=np.int32)
+            rec = np.zeros((self.num_envs, self.record_bytes), dtype=np.uint8)
+            one = self._one = (acts, rec, acts.ctypes.data_as(C.c_void_p), rec.ctypes.data_as(C.c_void_p))
+        acts, rec, pa, pr = one
+        acts[game] = action
+        rc = self._L.skyjo_vec_step_host(self._h, pa, pr)
+        acts[game] = self.ACTION_SKIP
+        _lib.check(rc)
+        return rec[game]
+
     def observe_host(self, players=None):
         rec = self._host_records()
         pp = None

@@ -61,5 +61,12 @@ for _ in range(200):
     g._state = None
     _ = g.players_cards
 out["state_fetch_us"] = 1e6 * (time.perf_counter() - t0) / 200
+# the floor of one host-style call: a step in which the game is left alone (ACTION_SKIP) - launch + stream synchronisation, no Python around it
+eng = g._engine
+if hasattr(eng, "step_one"):
+    t0 = time.perf_counter()
+    for _ in range(3000):
+        eng.step_one(0, eng.ACTION_SKIP)
+    out["native_call_floor_us"] = 1e6 * (time.perf_counter() - t0) / 3000
 out["reference_constants"] = {"env_steps_per_s": 6.9e3, "core_steps_per_s": 8.3e3, "source": "BASELINE.md section 2"}
 print(json.dumps(out))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): bash tools/refresh_profiles.sh
 # One pass of everything profiles/ is digested from (tools/collect_profiles.py reads gpurun_out/final/ afterwards):
-#   bench.json            python bench.py                       (the default line)
+#   bench.json            python bench.py --steps 20 --warmup 5 (the line as the driver asks for it, every BASELINE config in other_configs)
 #   trace/                rocprofv3 --kernel-trace --stats      (short bench run)
 #   pmc_fetch|write|sq|sq2|ea|l2/   rocprofv3 --kernel-trace --pmc ...    (separate passes, nothing else traced)
 set -u
@@ -9,18 +9,18 @@ root=$PWD
 out=$root/gpurun_out/final
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
-python3 bench.py > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?"
+python3 bench.py --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" --steps 100 --warmup 10 --no-cpu-baseline > "$out/trace_bench.json" 2> "$out/trace.err"; echo "trace rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" --steps 100 --warmup 10 --blocks 2 --no-cpu-baseline --no-other-configs > "$out/trace_bench.json" 2> "$out/trace.err"; echo "trace rc=$?"
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "sq2 SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS" "ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "l2 TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum TCC_MISS_sum"; do
   set -- $pass; tag=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/pmc_$tag" -- python3 "$root/bench.py" --steps 30 --warmup 10 --no-cpu-baseline > "$out/pmc_$tag.json" 2> "$out/pmc_$tag.err"; echo "pmc $tag rc=$?"
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/pmc_$tag" -- python3 "$root/bench.py" --steps 30 --warmup 10 --blocks 1 --no-cpu-baseline --no-other-configs > "$out/pmc_$tag.json" 2> "$out/pmc_$tag.err"; echo "pmc $tag rc=$?"
 done
 # config 5 (65 536 x 4 players, the action-mask model on the matrix cores picks every action): bench line + kernel stats
 cd "$root"
-python3 tools/bench_cfg5.py 65536 300 > "$out/cfg5.json" 2> "$out/cfg5.err"; echo "cfg5 rc=$?"
+python3 tools/bench_cfg5.py 65536 64 8 > "$out/cfg5.json" 2> "$out/cfg5.err"; echo "cfg5 rc=$?"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_cfg5" -- python3 "$root/tools/bench_cfg5.py" 65536 100 mfma > "$out/cfg5_trace.json" 2> "$out/cfg5_trace.err"; echo "cfg5 trace rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_cfg5" -- python3 "$root/tools/bench_cfg5.py" 65536 64 4 > "$out/cfg5_trace.json" 2> "$out/cfg5_trace.err"; echo "cfg5 trace rc=$?"
 cd "$root"
 # keep the merge-back small: only the csv summaries
 find "$out" -type f ! -name "*.csv" ! -name "*.json" ! -name "*.err" -delete
