@@ -139,7 +139,7 @@ def time_rollout(eng, chunk, launches, rec, sync):
     return dt, eng.counters()
 
 
-def side_rollout_config(name, B, N, steps, warmup, device, rng_mode, indirect=True, game_id0=0, settle=40):
+def side_rollout_config(name, B, N, steps, warmup, device, rng_mode, indirect=True, game_id0=0, settle=100):
     """One of the other BASELINE configurations as a short block in the same process: value, time per lockstep iteration, the
     dominant kernel's launch time (HIP events) and its roofline fraction (SURVEY 8d bytes of that shape)."""
     import torch
@@ -157,7 +157,8 @@ def side_rollout_config(name, B, N, steps, warmup, device, rng_mode, indirect=Tr
     if chunk2 != chunk:
         chunk = chunk2
         rec = eng.new_records(chunk)
-    dt, c = time_rollout(eng, chunk, steps, rec, sync)
+    runs = sorted((time_rollout(eng, chunk, steps, rec, sync) for _ in range(3)), key=lambda x: x[0])
+    dt, c = runs[1]  # the median of three blocks
     eng.profile(1)
     for _ in range(16):
         eng.rollout(chunk, policy_seed=1, records=rec)
@@ -192,14 +193,19 @@ def side_model_config(precision, B, N, T, rounds, device):
     buf = RolloutBuffer(env, T)
     collect(env, pol, val, buf, seed=9, first_ticket=0)  # warm-up (incl. the first episodes' common end)
     collect(env, pol, val, buf, seed=9, first_ticket=T, first_records=buf.records[T].clone())
-    torch.cuda.synchronize()
-    env.reset_counters()
-    t0 = time.perf_counter()
-    for r in range(rounds):
-        collect(env, pol, val, buf, seed=9, first_ticket=(2 + r) * T, first_records=buf.records[T].clone())
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    c = env.counters()
+    per_round = []  # (seconds, env-steps) of every timed round: the median one is reported (a round is ~3 ms: one hiccup of the
+    for r in range(rounds):  # host - an allocation, a page fault - would otherwise be the result)
+        first = buf.records[T].clone()
+        torch.cuda.synchronize()
+        env.reset_counters()
+        t0 = time.perf_counter()
+        collect(env, pol, val, buf, seed=9, first_ticket=(2 + r) * T, first_records=first)
+        torch.cuda.synchronize()
+        per_round.append((time.perf_counter() - t0, env.counters()))
+    per_round.sort(key=lambda x: x[0])
+    dt, c = per_round[len(per_round) // 2]
+    dt *= rounds  # (the fields below are written for `rounds` rounds of the median round's duration)
+    c = dict(c, steps=c["steps"] * rounds)
     env.profile(1)
     collect(env, pol, val, buf, seed=9, first_ticket=(2 + rounds) * T, first_records=buf.records[T].clone())
     prof = env.profile(0)
@@ -213,7 +219,8 @@ def side_model_config(precision, B, N, T, rounds, device):
            "roofline_bound": "mfma", "roofline_achieved_tflops": flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else None,
            "roofline_frac": flops / (mlp_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS if mlp_ms > 0 else None,
            "mfma_issue_frac": (3.0 if precision == "fp32" else 1.0) * flops / (mlp_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS if mlp_ms > 0 else None,
-           "illegal": int(c["illegal"]), "mean_episode_len": c["sum_len"] / max(c["episodes"], 1)}
+           "illegal": int(c["illegal"]), "mean_episode_len": c["sum_len"] / max(c["episodes"], 1),
+           "round_ms": [1e3 * x[0] for x in per_round]}
     pol.close(), val.close(), env.close()
     return out
 
@@ -225,8 +232,8 @@ def other_configs(device, steps, warmup):
     for name, fn in (
             ("cfg2_4096x2", lambda: side_rollout_config("cfg2", 4096, 2, 4 * steps, warmup, device, RNG_MT19937)),
             ("cfg4_shard_32768x3", lambda: side_rollout_config("cfg4", 32768, 3, 2 * steps, warmup, device, RNG_MT19937, game_id0=3 * 32768)),
-            ("cfg5_65536x4_model_fp32", lambda: side_model_config("fp32", 65536, 4, 64, 4, device)),
-            ("cfg5_65536x4_model_bf16", lambda: side_model_config("bf16", 65536, 4, 64, 4, device)),
+            ("cfg5_65536x4_model_fp32", lambda: side_model_config("fp32", 65536, 4, 64, 7, device)),
+            ("cfg5_65536x4_model_bf16", lambda: side_model_config("bf16", 65536, 4, 64, 7, device)),
             ("philox_65536x3", lambda: side_rollout_config("philox", 65536, 3, steps, warmup, device, RNG_PHILOX)),
             ("direct_obs_65536x3", lambda: side_rollout_config("direct", 65536, 3, steps, warmup, device, RNG_MT19937, indirect=False))):
         try:
