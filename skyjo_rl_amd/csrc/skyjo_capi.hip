@@ -76,7 +76,7 @@ struct skyjo_vec {
   SkParams P{};
   size_t G = 0;           // tiles * 64
   size_t lds_bytes = 0, lds_tile = 0;
-  size_t lds_rollout = 0;  // the fused rollout kernels of 2 / 3 / 4 players keep their statistics in registers: smaller footprint
+  size_t lds_rollout = 0, lds_step = 0;  // the step kernels of 2 / 3 / 4 players keep their statistics in registers: smaller footprints (fused rollout / caller actions)
   bool seeded = false;
   int pending_iters = 0;  // lockstep iterations since the dealing kernel last ran
   int deal_every_iters = 64;  // set from deal_interval_default() in skyjo_vec_create
@@ -331,7 +331,7 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
   if ((rc = prof_events(h, 0, &e0, &e1))) return rc;
   if (h->deal_inflight && h->inflight_piped) h->P.ov_flags |= 1u;  // publish what has been dealt since (sk_publish_deals)
 #define LAUNCH3(I, Pol, NP)                                                                                       \
-  hipExtLaunchKernelGGL((k_step<I, Pol, NP>), grid, block, (uint32_t)(Pol ? h->lds_rollout : h->lds_bytes), s, e0, e1, 0, h->P, actions,   \
+  hipExtLaunchKernelGGL((k_step<I, Pol, NP>), grid, block, (uint32_t)(Pol ? h->lds_rollout : h->lds_step), s, e0, e1, 0, h->P, actions,   \
                         rec, act_out, iters, policy_seed, h->iter, end_rew, end_flag, raw_out, h->raw_stride)
 #define LAUNCH(I, Pol)                                \
   switch (h->P.L.N) {                                 \
@@ -430,14 +430,11 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   // aliases this area) + per-lane per-seat float64 statistics
   h->lds_bytes = h->lds_tile + (size_t)SK_TILE * (P.L.indirect ? 64 : P.L.rec_bytes + 16) + (size_t)SK_ACC_KINDS * cfg->num_players * 512 +
                  (cfg->num_players < 8 ? (size_t)cfg->num_players * 1024 : 0);  // + the card chunks of games waiting to be scored
-#ifdef SK_NO_REGACC
-  h->lds_rollout = h->lds_bytes;
-#else
-  h->lds_rollout = (cfg->num_players >= 2 && cfg->num_players <= 4)
-                       ? h->lds_tile + (size_t)SK_TILE * (P.L.indirect ? 64 : P.L.rec_bytes + 16) + (size_t)cfg->num_players * 1024
-                       : h->lds_bytes;
-#endif
-  if (const char *e = getenv("SKYJO_LDS_PAD")) h->lds_bytes += (size_t)atoi(e), h->lds_rollout += (size_t)atoi(e);  // diagnostic: caps the wavefronts per CU
+  const bool fixed_n = cfg->num_players >= 2 && cfg->num_players <= 4;
+  h->lds_step = fixed_n ? h->lds_tile + (size_t)SK_TILE * (P.L.indirect ? 64 : P.L.rec_bytes + 16) : h->lds_bytes;
+  h->lds_rollout = fixed_n ? h->lds_step + (size_t)cfg->num_players * 1024 : h->lds_bytes;
+  if (const char *e = getenv("SKYJO_LDS_PAD"))  // diagnostic: caps the wavefronts per CU
+    h->lds_bytes += (size_t)atoi(e), h->lds_rollout += (size_t)atoi(e), h->lds_step += (size_t)atoi(e);
   const size_t rec16 = (size_t)P.tiles * P.L.chunks * SK_TILE;
   if ((uint64_t)SK_BANK * rec16 * 16 >= (1ull << 32)) {  // (LDS-DMA addresses the bank with 32-bit offsets)
     delete h;
@@ -749,42 +746,51 @@ int skyjo_vec_step_collect(skyjo_vec *h, const int32_t *actions, void *records_o
   return step_once(h, actions, records_out, final_rewards_out, episode_end_out, (hipStream_t)stream);
 }
 
-int skyjo_vec_model_rollout(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, int32_t T, uint64_t seed,
-                            uint64_t first_ticket, int32_t no_masking, const skyjo_vec_rollout_buffers *b, void *stream) {
+// ---- config 5's collection loop (include/skyjo_vec.h: skyjo_vec_model_rollout) ----
+static int model_check(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, int32_t T, const skyjo_vec_rollout_buffers *b) {
   if (!h || !policy || !b || T < 0 || !b->records || !b->actions) return fail(SKYJO_E_INVALID, "skyjo_vec_model_rollout: bad argument");
   if (value && !b->values) return fail(SKYJO_E_INVALID, "skyjo_vec_model_rollout: a value net needs a values buffer");
   if ((b->final_rewards == nullptr) != (b->episode_end == nullptr))
     return fail(SKYJO_E_INVALID, "skyjo_vec_model_rollout: final_rewards and episode_end go together");
-  GUARD(h);
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   if (policy->net.out_dim != SKYJO_NUM_ACTIONS) return fail(SKYJO_E_INVALID, "the policy net needs 26 outputs");
   if (policy->device_id != h->cfg.device_id || policy->obs_dim != h->P.L.D || !h->P.L.indirect)
     return fail(SKYJO_E_INVALID, "the policy net must live on the engine's device and take the engine's (indirect) observation");
   if (value && (policy->obs_dim != value->obs_dim || policy->device_id != value->device_id || policy->net.split != value->net.split))
     return fail(SKYJO_E_INVALID, "policy and value net must share the observation size, the precision and the device");
-  hipStream_t s = (hipStream_t)stream;
-  const size_t B = (size_t)h->P.B, rb = (size_t)h->P.L.rec_bytes, N = (size_t)h->P.L.N;
-  const size_t vd = value ? (size_t)value->net.out_dim : 0;
-  uint8_t *rec = (uint8_t *)b->records;
-  int rc;
-  for (int t = 0; t < T; t++) {
-    SkMlpDraw d{};
-    d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = first_ticket + (uint64_t)t;
-    d.game_id0 = h->P.game_id0, d.actions = b->actions + (size_t)t * B, d.logp = b->logp ? b->logp + (size_t)t * B : nullptr;
-    if ((rc = launch_mlp(policy, value ? value : policy, value ? 2 : 1, rec + (size_t)t * B * rb, (int)rb, policy->obs_dim,
-                         (int64_t)B, nullptr, d, value ? b->values + (size_t)t * B * vd : nullptr, s, h)))
-      return rc;
-    if ((rc = step_once(h, b->actions + (size_t)t * B, rec + (size_t)(t + 1) * B * rb,
-                        b->final_rewards ? b->final_rewards + (size_t)t * B * N : nullptr, b->episode_end ? b->episode_end + (size_t)t * B : nullptr, s)))
-      return rc;
-  }
-  if (value) {  // the bootstrap value of the records the rollout ends on
-    SkMlpDraw nodraw{};
-    if ((rc = launch_mlp(value, value, 1, rec + (size_t)T * B * rb, (int)rb, value->obs_dim, (int64_t)B, b->values + (size_t)T * B * vd, nodraw,
-                         nullptr, s)))
-      return rc;
-  }
   return SKYJO_OK;
+}
+// iteration t: [policy (+ value) net with the draw in its epilogue] -> [step kernel with the episode-end columns]
+static int model_iter(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, int t, uint64_t seed, uint64_t first_ticket,
+                      int32_t no_masking, const skyjo_vec_rollout_buffers *b, hipStream_t s) {
+  const size_t B = (size_t)h->P.B, rb = (size_t)h->P.L.rec_bytes, N = (size_t)h->P.L.N, vd = value ? (size_t)value->net.out_dim : 0;
+  uint8_t *rec = (uint8_t *)b->records;
+  SkMlpDraw d{};
+  d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = first_ticket + (uint64_t)t;
+  d.game_id0 = h->P.game_id0, d.actions = b->actions + (size_t)t * B, d.logp = b->logp ? b->logp + (size_t)t * B : nullptr;
+  int rc = launch_mlp(policy, value ? value : policy, value ? 2 : 1, rec + (size_t)t * B * rb, (int)rb, policy->obs_dim, (int64_t)B, nullptr, d,
+                      value ? b->values + (size_t)t * B * vd : nullptr, s, h);
+  if (rc) return rc;
+  return step_once(h, b->actions + (size_t)t * B, rec + (size_t)(t + 1) * B * rb, b->final_rewards ? b->final_rewards + (size_t)t * B * N : nullptr,
+                   b->episode_end ? b->episode_end + (size_t)t * B : nullptr, s);
+}
+// the bootstrap value of the records a rollout ends on
+static int model_tail(skyjo_vec *h, const skyjo_vec_mlp *value, int T, const skyjo_vec_rollout_buffers *b, hipStream_t s) {
+  if (!value) return SKYJO_OK;
+  const size_t B = (size_t)h->P.B, rb = (size_t)h->P.L.rec_bytes, vd = (size_t)value->net.out_dim;
+  SkMlpDraw nodraw{};
+  return launch_mlp(value, value, 1, (const uint8_t *)b->records + (size_t)T * B * rb, (int)rb, value->obs_dim, (int64_t)B, b->values + (size_t)T * B * vd,
+                    nodraw, nullptr, s);
+}
+
+int skyjo_vec_model_rollout(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, int32_t T, uint64_t seed,
+                            uint64_t first_ticket, int32_t no_masking, const skyjo_vec_rollout_buffers *b, void *stream) {
+  int rc = model_check(h, policy, value, T, b);
+  if (rc) return rc;
+  GUARD(h);
+  for (int t = 0; t < T; t++)
+    if ((rc = model_iter(h, policy, value, t, seed, first_ticket, no_masking, b, (hipStream_t)stream))) return rc;
+  return model_tail(h, value, T, b, (hipStream_t)stream);
 }
 
 int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *records_out, int32_t *actions_out,

@@ -1186,15 +1186,12 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   uint8_t *stg = (uint8_t *)lds_raw + P.L.chunks * 1024;
   uint8_t *fp = stg + lane * 4;
   uint8_t *ap = stg + (INDIRECT ? 4096 : SK_TILE * (P.L.rec_bytes + 16)) + lane * 8;
-  // deferred scoring (fixed player counts under the on-device policy): one card chunk per player and lane.  Those kernels
-  // keep the per-seat statistics in registers (REGACC) - their LDS is tile | staging | card chunks, nothing else: at three
-  // players 25 KB per wavefront, so that four dealing wavefronts (14.75 KB each) fit beside a CU's four step wavefronts.
+  // deferred scoring (fixed player counts under the on-device policy): one card chunk per player and lane.  The kernels with
+  // a compile-time player count keep the per-seat statistics in registers (REGACC: fewer LDS atomics, -2 % for the fused
+  // rollout, -8 % for a step with caller actions) - their LDS is tile | staging (| card chunks of the deferred scoring),
+  // nothing else: 25 KB per wavefront for the fused rollout at three players.
   constexpr bool DEFER = POLICY && NP > 0 && NP < 8;
-#ifdef SK_NO_REGACC
-  constexpr bool REGACC = false;
-#else
-  constexpr bool REGACC = DEFER;
-#endif
+  constexpr bool REGACC = NP > 0 && NP < 8;  // (every kernel with a compile-time player count)
   constexpr int NACC = REGACC ? SK_ACC_KINDS * NP : 1;
   double racc_store[NACC];
 #pragma unroll

@@ -93,3 +93,4 @@ def test_native_rollout_call_equals_the_stepwise_loop_and_the_separate_episode_e
         env.close()
     for a, b in zip(*cols):
         assert torch.equal(a, b)
+
