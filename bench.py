@@ -10,7 +10,7 @@ with the applied action written to HBM) and finished games take their next deal 
 run (k_deal) that the engine starts once per 88 iterations.  So `--steps 20 --warmup 5` are 1 760
 timed lockstep iterations after 440 untimed ones (about 16 episodes per game inside a timed block).
 Before the warm-up the freshly seeded games are run for 100 launches (set-up: seeded together they
-end their first episodes together).
+end their first episodes together, EXPERIMENTS.md round 2).
 
 Workload (`--config 3`, the default): BASELINE.json configs[2], 65 536 parallel 3-player games per GPU
 (weak scaling under --gpus N), DEFAULT_CONFIG (indirect observation, D = 31), game g seeded base + g,

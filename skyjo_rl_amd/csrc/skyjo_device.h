@@ -631,8 +631,8 @@ __device__ __forceinline__ void finish_game(const SkParams &P, uint8_t *lp, uint
 // The same for a compile-time player count: card rows come in as dwords, scores stay in registers.  `rows`: this lane's
 // card chunk of player 0, player p's `stride` bytes further - the live tile, or the copy a deferred scoring works on.
 // `racc` != nullptr: the per-seat statistics are kept in the lane's REGISTERS (SK_ACC_KINDS x NP doubles, constant indices
-// after unrolling) instead of the LDS slots behind `ap` - the fused rollout kernels, whose LDS footprint decides how many
-// dealing wavefronts fit beside them on a CU (25 KB instead of 31 KB at three players).
+// after unrolling) instead of the LDS slots behind `ap`: no LDS atomics, and 6 KB less LDS per wavefront at three players
+// (the step kernels with a compile-time player count; EXPERIMENTS.md round 3).
 template <int NP>
 __device__ __forceinline__ void finish_game_fixed(const SkParams &P, const uint8_t *rows, int stride, uint8_t *ap, int g, int finisher,
                                                   double *racc = nullptr) {
@@ -1674,7 +1674,7 @@ struct MtChunkStream {
   // the chunk after it.
   //
   // The dealing kernel is bound by the memory system (5.3 TB/s of 128-byte line reads and 64-byte write-backs at the
-  // fabric), and most sensitive to how the state is WRITTEN: stored by its owner, a chunk is four
+  // fabric, EXPERIMENTS.md), and most sensitive to how the state is WRITTEN: stored by its owner, a chunk is four
   // 16-byte pieces in four instructions, each of which scatters 64 pieces over 64 lines.  So the wavefront writes
   // TOGETHER: every lane puts its chunk and its address into its staging row in LDS, and store instruction k is lane i
   // writing piece i & 3 of the lane 16 k + (i >> 2) - four neighbouring lanes one whole 64-byte line, a quarter of the
