@@ -65,6 +65,7 @@ struct SkParams {
   uint32_t *plan_ep;        // [tiles*64] episode index of that deal (pipelined dealing: see sk_plan_deals)
   uint32_t ov_flags;        // k_step, dealing beside it: 1 = publish finished deals on the way in, 2 = plan the next run on the way out
   uint32_t plan_new_tag;    // the id the planned run will have
+  uint32_t host_seq;        // != 0 (single-tile engines, host-style step): the wavefront's last store is this number into health_host[3]
   int32_t *deal_list;       // [2][tiles*64] games of the current / previous dealing launch (k_scan)
   uint32_t *deal_ep;        // [2][tiles*64] episode index of each listed deal
   uint32_t *deal_count;     // [2]
@@ -1399,7 +1400,16 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   HDR_FLUSH(h);
   tile_store_nt(P, P.state, tile, lane, lp);
   if (!POLICY && raw_out && valid) sk_export_raw(P, lp, g, raw_out + (size_t)g * raw_stride);
-  if (!POLICY) sk_error_to_host(P);
+  if (!POLICY) {
+    sk_error_to_host(P);
+    if (P.host_seq) {
+      // ONE tile = this wavefront is the whole launch: everything the host reads back (records, exported games, error word)
+      // has been stored by it - make that visible system-wide, then tell the host, which is spinning on the word instead of
+      // paying for a stream synchronisation (skyjo_vec_step_host)
+      __threadfence_system();
+      if (lane == 0) __hip_atomic_store(&P.health_host[3], P.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   if (P.ov_flags & 2u) {
     // (first what the run beside THIS launch has dealt: a game whose busy mark outlived the launch in which it is dealt would
     // get a new episode only every second run.  The dealing kernel was started before this launch and is as good as through:
