@@ -1,0 +1,37 @@
+"""CPU: the arithmetic bench.py's roofline objects rest on, and its refusal to let ranks share a card silently."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_algorithmic_bytes_follow_survey_8d():
+    import bench
+
+    # S(N) = 24 N + 150 + 16 read once and written once per launch; per env-step D obs + 26 mask + 2 (agent, done) + 1 action byte
+    assert bench.algorithmic_bytes_per_launch(1, 3, 31, 1) == 2 * 238 + 60
+    assert bench.algorithmic_bytes_per_launch(65536, 3, 31, 88) == 377225216  # 377.2 MB per launch
+    assert bench.algorithmic_bytes_per_launch(65536, 2, 31, 64, records=False) == 65536 * 2 * 214
+    # one step per launch with an int32 action in and no fused state: SURVEY's 539 B/step at N = 3 is 4 + 31 + 26 + 2 + 2 * 238
+    assert 4 + 31 + 26 + 2 + 2 * 238 == 539
+
+
+def test_expected_rng_outputs_per_deal():
+    import bench
+
+    # shuffle(150) + shuffle(150 - 12 N) + N x permutation(12) with numpy's masked rejection sampling
+    n3 = bench.rng_outputs_per_deal(3)
+    assert 410 < n3 < 420  # 415 outputs on average at three players (profiles: rng_outputs_per_deal)
+    assert bench.rng_outputs_per_deal(2) > n3 - 40 and bench.rng_outputs_per_deal(4) < n3 + 40
+
+
+def test_bench_without_a_gpu_fails_loudly():
+    """bench.py is the product path: on a box without a GPU it must fail, not fall back to anything."""
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode != 0 and "needs a GPU" in (out.stderr + out.stdout)
