@@ -509,9 +509,15 @@ int sko_policy_action(uint64_t policy_seed, uint64_t game_id, uint64_t iter, con
   return 24;
 }
 
-void sko_vec_rollout(sko_vec *v, int iters, uint64_t policy_seed, int32_t *actions_out, int threads) {
+/* The same, and what the engine's record of every iteration holds (include/skyjo_vec.h: observation and action mask of the
+ * player expected next, skyjo.py:148-224; agent, phase, done, status; steps applied in the episode), observed AFTER the
+ * iteration's step: obs_out [iters][B][D], mask_out [iters][B][26], meta_out [iters][B][4], eplen_out [iters][B]. */
+void sko_vec_rollout_rec(sko_vec *v, int iters, uint64_t policy_seed, int32_t *actions_out, int8_t *obs_out, int8_t *mask_out,
+                         uint8_t *meta_out, uint16_t *eplen_out, int threads) {
   uint64_t steps = 0, episodes = 0, illegal = 0, resets = 0, sum_len = 0;
   const uint64_t iter0 = v->iter;
+  const int D = v->indirect ? 31 : 19 + 12 * v->num_players;
+  const size_t B = (size_t)v->num_envs;
 #pragma omp parallel for num_threads(threads > 0 ? threads : 1) reduction(+ : steps, episodes, illegal, resets, sum_len) schedule(static)
   for (int i = 0; i < v->num_envs; i++) {
     for (int t = 0; t < iters; t++) {
@@ -522,9 +528,21 @@ void sko_vec_rollout(sko_vec *v, int iters, uint64_t policy_seed, int32_t *actio
         a = sko_policy_action(policy_seed, v->game_id0 + (uint64_t)i, iter0 + (uint64_t)t, mask);
       }
       vec_step_one(v, i, a, &steps, &episodes, &illegal, &resets, &sum_len);
-      if (actions_out) actions_out[(size_t)t * v->num_envs + i] = a;
+      if (actions_out) actions_out[(size_t)t * B + i] = a;
+      if (obs_out) {
+        const sko_game *g = &v->games[i];
+        const size_t at = (size_t)t * B + (size_t)i;
+        sko_observe(g, g->exp_player, obs_out + at * (size_t)D, mask_out + at * 26);
+        meta_out[at * 4 + 0] = (uint8_t)g->exp_player, meta_out[at * 4 + 1] = (uint8_t)g->exp_phase;
+        meta_out[at * 4 + 2] = v->done[i], meta_out[at * 4 + 3] = v->status[i];
+        eplen_out[at] = (uint16_t)v->ep_len[i];
+      }
     }
   }
   v->iter += (uint64_t)iters;
   v->steps += steps, v->episodes += episodes, v->illegal += illegal, v->resets += resets, v->sum_len += sum_len;
+}
+
+void sko_vec_rollout(sko_vec *v, int iters, uint64_t policy_seed, int32_t *actions_out, int threads) {
+  sko_vec_rollout_rec(v, iters, policy_seed, actions_out, NULL, NULL, NULL, NULL, threads);
 }

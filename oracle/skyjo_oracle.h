@@ -10,7 +10,7 @@
  * init_genrand / random_interval / Fisher-Yates) which the reference consumes through
  * np.random.seed/shuffle/choice (skyjo.py:81,94,101,135).
  *
- * Pinning: every function here is checked against tests/golden/*.npz, which were produced by
+ * Pinning: every function here is checked against the .npz fixtures under tests/golden/, which were produced by
  * running the real reference in the build container (oracle/gen_golden.py).  Nothing under
  * skyjo_rl_amd/ may include, link or call this file; only tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg do.
@@ -134,6 +134,8 @@ void sko_vec_observe(const sko_vec *v, const int32_t *players, int8_t *obs, int8
                      uint8_t *phase);
 /* K lockstep iterations with the on-device uniform-random admissible policy restated */
 void sko_vec_rollout(sko_vec *v, int iters, uint64_t policy_seed, int32_t *actions_out, int threads);
+void sko_vec_rollout_rec(sko_vec *v, int iters, uint64_t policy_seed, int32_t *actions_out, int8_t *obs_out, int8_t *mask_out,
+                         uint8_t *meta_out, uint16_t *eplen_out, int threads); /* + every iteration's record */
 int sko_policy_action(uint64_t policy_seed, uint64_t game_id, uint64_t iter, const int8_t *mask);
 
 #ifdef __cplusplus

@@ -75,6 +75,8 @@ def lib():
         L.sko_vec_step.argtypes = [C.POINTER(Vec), C.c_void_p, C.c_int]
         L.sko_vec_observe.argtypes = [C.POINTER(Vec), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sko_vec_rollout.argtypes = [C.POINTER(Vec), C.c_int, C.c_uint64, C.c_void_p, C.c_int]
+        L.sko_vec_rollout_rec.argtypes = [C.POINTER(Vec), C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int]
         L.sko_policy_action.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
         L.sko_final_rewards.argtypes = [C.POINTER(Game), C.c_double, C.c_double, C.c_void_p]
         L.sko_evaluate_game.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
@@ -206,10 +208,21 @@ class OracleVec:
         a = np.ascontiguousarray(actions, dtype=np.int32)
         self.L.sko_vec_step(self.v, _p(a), threads)
 
-    def rollout(self, iters, policy_seed, threads=1, record_actions=False):
-        acts = np.zeros((iters, self.num_envs), dtype=np.int32) if record_actions else None
-        self.L.sko_vec_rollout(self.v, iters, int(policy_seed), _p(acts), threads)
-        return acts
+    def rollout(self, iters, policy_seed, threads=1, record_actions=False, record_obs=False):
+        """`iters` lockstep iterations with the restated on-device policy.  record_obs: also what the engine's record of EVERY
+        iteration holds - returns (actions, obs [iters, B, D], mask [iters, B, 26], meta [iters, B, 4] = agent, phase, done,
+        status, episode_steps [iters, B])."""
+        acts = np.zeros((iters, self.num_envs), dtype=np.int32) if (record_actions or record_obs) else None
+        if not record_obs:
+            self.L.sko_vec_rollout(self.v, iters, int(policy_seed), _p(acts), threads)
+            return acts
+        B = self.num_envs
+        obs = np.zeros((iters, B, self.obs_dim), dtype=np.int8)
+        mask = np.zeros((iters, B, 26), dtype=np.int8)
+        meta = np.zeros((iters, B, 4), dtype=np.uint8)
+        eplen = np.zeros((iters, B), dtype=np.uint16)
+        self.L.sko_vec_rollout_rec(self.v, iters, int(policy_seed), _p(acts), _p(obs), _p(mask), _p(meta), _p(eplen), threads)
+        return acts, obs, mask, meta, eplen
 
     def observe(self, players=None):
         B = self.num_envs

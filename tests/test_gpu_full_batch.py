@@ -2,14 +2,17 @@
 re-simulated a 192- or 256-game window).  The OpenMP oracle (oracle/skyjo_oracle.c, `threads=`) replays every game of
 the batch from its global id alone; compared bit for bit, for all B games:
 
-  * the action byte of EVERY record of every iteration (the on-device policy's pick = the oracle's restatement of it,
-    which pins the mask it was drawn from and, through the episode that follows, every card that was dealt or moved),
-  * the whole last record of every launch (observation, action mask, agent, phase, done, status),
-  * the counters at the end (steps, episodes, resets, sum of episode lengths).
+  * EVERY record of every iteration of every launch, whole (VERDICT r3 "weak" #1: the fused rollout stages each iteration's
+    records in an LDS area that the rare paths' RNG scratch aliases, so the last record of a launch alone proves nothing
+    about the others): observation, action mask, the applied action (byte D), agent, phase, done, status, episode steps
+    (skyjo.py:148-224 observed after each step: OracleVec.rollout(record_obs=True)),
+  * the counters at the end (steps, episodes, resets, sum of episode lengths), final rewards of the games that stand finished.
 
 Cases: config 3 (65 536 x 3, MT19937), the config-4 shard (32 768 x 3 with game_id0 = 3 * 32 768, dealing beside the step
 kernel), config 2 (4 096 x 2), the counter-based mode, the direct observation, and the generic-N kernels (k_step<.., 0>,
-k_deal<0>) with 5 / 8 / 12 players at 65 536 games.  Config 5's env side (actions drawn by the policy net, fed back to the
+k_deal<0>) with 5 / 8 / 12 players at 65 536 games (12 players: ~17 mid-game reshuffles per episode, whose generator
+scratch is the aliased area), and a batch whose dealing interval is set to 1 000 iterations so that the banks run dry and
+the games deal in place inside the step kernel (deal_inline, the other user of that scratch).  Config 5's env side (actions drawn by the policy net, fed back to the
 oracle, every record compared) is test_config5_env_side_every_record.
 """
 import os
@@ -27,20 +30,22 @@ def _cfg(N, ind, rng_mode):
 
 
 CASES = [
-    # name            B      N  indirect rng game_id0   launches x iterations
-    ("cfg3_headline", 65536, 3, True, 0, 0, 6, 64),          # 384 iterations: ~3.6 episodes per game
-    ("cfg4_shard", 32768, 3, True, 0, 3 * 32768, 6, 64),
-    ("cfg2", 4096, 2, True, 0, 0, 5, 64),
-    ("philox", 65536, 3, True, 1, 0, 4, 64),
-    ("direct_obs", 65536, 3, False, 0, 0, 4, 64),
-    ("generic_N5", 65536, 5, True, 0, 0, 5, 64),
-    ("generic_N8_philox_direct", 65536, 8, False, 1, 0, 6, 64),
-    ("generic_N12", 65536, 12, True, 0, 0, 7, 64),   # ~17 mid-game reshuffles per episode (stream roll-backs)
+    # name            B      N  indirect rng game_id0   launches x iterations, dealing interval (0: the engine's own)
+    ("cfg3_headline", 65536, 3, True, 0, 0, 6, 64, 0),          # 384 iterations: ~3.6 episodes per game
+    ("cfg4_shard", 32768, 3, True, 0, 3 * 32768, 6, 64, 0),
+    ("cfg2", 4096, 2, True, 0, 0, 5, 64, 0),
+    ("philox", 65536, 3, True, 1, 0, 4, 64, 0),
+    ("direct_obs", 65536, 3, False, 0, 0, 4, 64, 0),
+    ("generic_N5", 65536, 5, True, 0, 0, 5, 64, 0),
+    ("generic_N8_philox_direct", 65536, 8, False, 1, 0, 6, 64, 0),
+    ("generic_N12", 65536, 12, True, 0, 0, 7, 64, 0),   # ~17 mid-game reshuffles per episode (stream roll-backs)
+    ("inplace_deals_interval1000", 16384, 3, True, 0, 0, 9, 64, 1000),  # the banks run dry after three episodes: deal_inline
+    ("inplace_deals_generic_N5", 8192, 5, True, 0, 0, 15, 64, 1024),
 ]
 
 
-@pytest.mark.parametrize("name,B,N,ind,rng_mode,gid0,launches,K", CASES, ids=[c[0] for c in CASES])
-def test_every_game_of_the_batch_against_the_oracle(name, B, N, ind, rng_mode, gid0, launches, K):
+@pytest.mark.parametrize("name,B,N,ind,rng_mode,gid0,launches,K,interval", CASES, ids=[c[0] for c in CASES])
+def test_every_game_of_the_batch_against_the_oracle(name, B, N, ind, rng_mode, gid0, launches, K, interval):
     import torch
     from oracle import skyjo_oracle as so
     from skyjo_rl_amd import SkyjoVecEnv
@@ -48,28 +53,33 @@ def test_every_game_of_the_batch_against_the_oracle(name, B, N, ind, rng_mode, g
     cfg = _cfg(N, ind, rng_mode)
     eng = SkyjoVecEnv(B, game_id0=gid0, **cfg)
     ora = so.OracleVec(num_envs=B, game_id0=gid0, **cfg)
+    if interval:
+        eng.set_deal_interval(interval)
     eng.seed(None, 0)
     ora.seed(None, 0)
     rec = eng.new_records(K)
     for r in range(launches):
         eng.rollout(K, policy_seed=1, records=rec)
-        oact = ora.rollout(K, 1, threads=THREADS, record_actions=True)
+        oact, obs, mask, meta, eplen = ora.rollout(K, 1, threads=THREADS, record_obs=True)
         v = eng.split(rec)
-        got = v.action.cpu().numpy()
-        np.testing.assert_array_equal(got, oact.astype(np.int8), err_msg=f"{name}: action bytes, launch {r}")
-        obs, mask, agent, phase = ora.observe()
-        np.testing.assert_array_equal(v.observations[K - 1].cpu().numpy(), obs, err_msg=f"{name}: last obs, launch {r}")
-        np.testing.assert_array_equal(v.action_mask[K - 1].cpu().numpy(), mask, err_msg=f"{name}: last mask, launch {r}")
-        np.testing.assert_array_equal(v.agent[K - 1].cpu().numpy(), agent)
-        np.testing.assert_array_equal(v.phase[K - 1].cpu().numpy(), phase)
-        np.testing.assert_array_equal(v.done[K - 1].cpu().numpy(), ora.dones)
-        np.testing.assert_array_equal(v.status[K - 1].cpu().numpy(), ora.status)
+        # every one of the K x B records, whole
+        np.testing.assert_array_equal(v.action.cpu().numpy(), oact.astype(np.int8), err_msg=f"{name}: action bytes, launch {r}")
+        np.testing.assert_array_equal(v.observations.cpu().numpy(), obs, err_msg=f"{name}: observations, launch {r}")
+        np.testing.assert_array_equal(v.action_mask.cpu().numpy(), mask, err_msg=f"{name}: action masks, launch {r}")
+        np.testing.assert_array_equal(v.agent.cpu().numpy(), meta[..., 0], err_msg=f"{name}: agent, launch {r}")
+        np.testing.assert_array_equal(v.phase.cpu().numpy(), meta[..., 1], err_msg=f"{name}: phase, launch {r}")
+        np.testing.assert_array_equal(v.done.cpu().numpy(), meta[..., 2], err_msg=f"{name}: done, launch {r}")
+        np.testing.assert_array_equal(v.status.cpu().numpy(), meta[..., 3], err_msg=f"{name}: status, launch {r}")
+        np.testing.assert_array_equal(v.episode_steps.cpu().numpy().astype(np.uint16), eplen, err_msg=f"{name}: episode steps, launch {r}")
+        del obs, mask, meta, eplen
     c, oc = eng.counters(), ora.counters()
     for k in ("steps", "episodes", "illegal", "resets", "sum_len"):
         assert c[k] == oc[k], (name, k, c[k], oc[k])
     assert c["steps"] + c["resets"] == launches * K * B and c["illegal"] == 0
     assert c["episodes"] > B // 2
-    if N <= 4:
+    if interval:
+        assert c["waits"] > B // 2, (name, c["waits"])  # (the case exists for the in-place deals)
+    elif N <= 4:
         assert c["waits"] == 0
     # final rewards of the games that stand finished right now (float64, ==)
     dn = ora.dones.astype(bool)
