@@ -183,7 +183,9 @@ const uint8_t *skyjo_vec_done_ptr(const skyjo_vec *h);
 /* Sticky device error of the handle: 0, or SKYJO_E_DEVICE with the reason in skyjo_vec_last_error() - today the one case
  * is a step kernel that gave up waiting for the dealing kernel that should run beside it (SKYJO_OPT_OVERLAP); the games
  * concerned show SKYJO_ST_ERROR once (the stream the dealing kernel may still hold is left alone), results since then
- * are void, skyjo_vec_seed clears it.  Synchronises `stream`.
+ * are void, skyjo_vec_seed clears it (and skyjo_vec_snapshot_restore: a snapshot is only ever taken of a clean run).  A game
+ * whose in-place deal or reset timed out shows done / SKYJO_ST_ERROR (not RESET; no reset is counted), its rewards are zero.
+ * Synchronises `stream`.
  * Every synchronising call below (and the *_host conveniences, snapshot_create) makes the same check by itself. */
 int skyjo_vec_check_error(skyjo_vec *h, void *stream);
 
@@ -200,7 +202,10 @@ int skyjo_vec_seed_raw(skyjo_vec *h, int32_t game, uint32_t value, void *stream)
  * MT19937 mode with SKYJO_OPT_NO_BANK these two calls move that stream in and out of one game in numpy's own terms -
  * np.random.get_state(): key uint32[624], pos 0..624 - so a single-game view can hand the caller's stream to the device
  * before a deal or a reshuffle and hand it back afterwards (skyjo_rl_amd/game.py: SkyjoGame(global_rng=True)).
- * get_state returns the block completed the way numpy keeps it (the engine regenerates the state lazily).  Both synchronise. */
+ * get_state returns the block completed the way numpy keeps it (the engine regenerates the state lazily).  Both synchronise.
+ * (This is the reference's behaviour with numba's JIT DISABLED - the mode its seeded test pins.  Jitted, the reference's
+ * np.random calls use numba's private generator and never touch the caller's global stream; a view in this mode re-seeds
+ * and advances the caller's stream instead: skyjo_rl_amd/game.py, module docstring.) */
 int skyjo_vec_rng_set_state(skyjo_vec *h, int32_t game, const uint32_t *key_host, int32_t pos, void *stream);
 int skyjo_vec_rng_get_state(skyjo_vec *h, int32_t game, uint32_t *key_out_host, int32_t *pos_out_host, void *stream);
 

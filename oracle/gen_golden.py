@@ -29,6 +29,12 @@ inputs -> outputs of the hot path:
                    come out of the one stream, in the order the loops make them; the stream's state is
                    recorded at every episode end
 
+  policy_stats.npz the reference's random admissible policy in numbers: for N in {2, 3, 4}, 6 000 games of SkyjoGame played
+                   by policy_ra (random_admissible_policy.py:26-28: choice(arange(26), p=mask/sum(mask))) - per game the
+                   episode length, per seat the final score and num_refunded; per place / draw turn the rank of the
+                   chosen action among the legal ones, counted by the number of legal actions.  The on-device policy
+                   (a different random stream by construction) is held to these distributions (tests/test_gpu_policy_stats.py)
+
 The fixtures are data (inputs and expected outputs) - no reference source text is stored.
 """
 import itertools
@@ -595,7 +601,45 @@ def gen_render():
     return len(names)
 
 
+def gen_policy_stats(games=6000):
+    """Statistics of the reference's own loop: SkyjoGame + policy_ra, default settings (score_penalty 2, indirect
+    observation - neither changes the play of a random policy), N = 2, 3, 4."""
+    out = {}
+    for N in (2, 3, 4):
+        np.random.seed(1000 + N)              # deals and reshuffles: the process-global legacy stream (skyjo.py:81,101,135)
+        rng = np.random.default_rng(77 + N)   # the policy's own generator (random_admissible_policy.py:24-25)
+        g = SkyjoGame(num_players=N, score_penalty=2.0, observe_other_player_indirect=True)
+        ep_len = np.zeros(games, dtype=np.int32)
+        score = np.zeros((games, N), dtype=np.float64)
+        refunded = np.zeros((games, N), dtype=np.int32)
+        rank_counts = np.zeros((27, 26), dtype=np.int64)   # [number of legal actions][rank of the chosen one among them]
+        for e in range(games):
+            g.reset()
+            steps = 0
+            while True:
+                pid, _ = g.expected_action
+                obs, mask = g.collect_observation(pid)
+                a = int(policy_ra(obs, mask, rng))
+                m = np.asarray(mask) != 0
+                assert m[a]
+                rank_counts[int(m.sum()), int(m[:a].sum())] += 1
+                steps += 1
+                if g.act(pid, a):
+                    break
+            met = g.get_game_metrics()
+            ep_len[e] = steps
+            score[e] = np.asarray(met["final_score"], dtype=np.float64)
+            refunded[e] = np.asarray(met["num_refunded"], dtype=np.int32)
+        out[f"N{N}_ep_len"], out[f"N{N}_score"], out[f"N{N}_refunded"], out[f"N{N}_rank_counts"] = ep_len, score, refunded, rank_counts
+    out["players"] = np.asarray([2, 3, 4], dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, "policy_stats.npz"), **out)
+    return {f"N{N}": (float(out[f"N{N}_ep_len"].mean()), float(out[f"N{N}_refunded"].sum(1).mean())) for N in (2, 3, 4)}
+
+
 def main():
+    if "--policy-stats-only" in sys.argv:
+        print("policy_stats", gen_policy_stats())
+        return
     if "--render-only" in sys.argv:
         print("render", gen_render())
         return
@@ -630,6 +674,7 @@ def main():
     print("env", gen_env(dict(skyjo_env.DEFAULT_CONFIG), 3, "env_illegal_place_s3", illegal_at=7, illegal_action=25))
     print("render", gen_render())
     print("global", gen_global())
+    print("policy_stats", gen_policy_stats())
     sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden bytes", sz)
 

@@ -391,13 +391,15 @@ sko_vec *sko_vec_create(int num_envs, int num_players, double score_penalty, int
   v->status = (uint8_t *)calloc((size_t)num_envs, 1);
   v->rewards = (double *)calloc((size_t)num_envs * (size_t)num_players, sizeof(double));
   v->ep_len = (uint32_t *)calloc((size_t)num_envs, sizeof(uint32_t));
+  v->acc_score = (double *)calloc((size_t)num_envs * (size_t)num_players, sizeof(double));
+  v->acc_refunded = (double *)calloc((size_t)num_envs * (size_t)num_players, sizeof(double));
   for (int i = 0; i < num_envs; i++) sko_init(&v->games[i], num_players, score_penalty, indirect, rng_mode);
   return v;
 }
 
 void sko_vec_destroy(sko_vec *v) {
   if (!v) return;
-  free(v->games), free(v->done), free(v->status), free(v->rewards), free(v->ep_len), free(v);
+  free(v->games), free(v->done), free(v->status), free(v->rewards), free(v->ep_len), free(v->acc_score), free(v->acc_refunded), free(v);
 }
 
 static void vec_new_episode(sko_vec *v, int i) {
@@ -467,6 +469,8 @@ static void vec_step_one(sko_vec *v, int i, int action, uint64_t *steps, uint64_
   (*steps)++;
   if (over > 0) { /* skyjo_env.py:242-247 */
     sko_final_rewards(g, v->mean_reward, v->reward_refunded, rew);
+    for (int p = 0; p < N; p++) /* per-seat statistics of the finished episodes (the engine's sum_score / sum_refunded) */
+      v->acc_score[(size_t)i * N + p] += g->final_score[p], v->acc_refunded[(size_t)i * N + p] += (double)g->num_refunded[p];
     v->done[i] = 1;
     (*episodes)++;
     (*sum_len) += v->ep_len[i];

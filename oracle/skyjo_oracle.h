@@ -121,6 +121,8 @@ typedef struct {
   uint64_t sum_len;
   uint64_t iter; /* lockstep iterations executed by sko_vec_rollout */
   uint32_t *ep_len;
+  double *acc_score;    /* [B][N] sums over the game's finished episodes: final score per seat ... */
+  double *acc_refunded; /* ... and num_refunded per seat */
 } sko_vec;
 
 sko_vec *sko_vec_create(int num_envs, int num_players, double score_penalty, int indirect, double mean_reward,

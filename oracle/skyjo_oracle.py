@@ -50,7 +50,7 @@ class Vec(C.Structure):
         ("games", C.POINTER(Game)), ("done", C.POINTER(C.c_uint8)), ("status", C.POINTER(C.c_uint8)),
         ("rewards", C.POINTER(C.c_double)), ("steps", C.c_uint64), ("episodes", C.c_uint64),
         ("illegal", C.c_uint64), ("resets", C.c_uint64), ("sum_len", C.c_uint64), ("iter", C.c_uint64),
-        ("ep_len", C.POINTER(C.c_uint32))]
+        ("ep_len", C.POINTER(C.c_uint32)), ("acc_score", C.POINTER(C.c_double)), ("acc_refunded", C.POINTER(C.c_double))]
 
 
 _lib = None
@@ -248,6 +248,12 @@ class OracleVec:
 
     def game(self, i):
         return self.v.contents.games[i]
+
+    def seat_sums(self):
+        """Sums over every finished episode since creation: (final score per seat, num_refunded per seat)."""
+        shp = (self.num_envs, self.num_players)
+        return (np.ctypeslib.as_array(self.v.contents.acc_score, shape=shp).sum(axis=0),
+                np.ctypeslib.as_array(self.v.contents.acc_refunded, shape=shp).sum(axis=0))
 
     def counters(self):
         c = self.v.contents

@@ -104,6 +104,8 @@ struct skyjo_vec {
   // launch + one stream synchronisation, and skyjo_vec_get_state / get_rewards_host afterwards are served from `hm_raw`
   // (raw_valid) without touching the device.
   bool fast_host = false, raw_valid = false;
+  bool host_spin = true;    // single-tile engines: spin on the kernel's sign-off word (SKYJO_NO_SPIN=1 at create time: synchronise the stream)
+  bool raw_export = false;  // the kernel also writes every game's packed state to host-mapped memory (few tiles only, see skyjo_vec_create)
   uint8_t *hm_block = nullptr;  // one hipHostMalloc: actions | mask | records | raw
   int32_t *hm_actions = nullptr;
   uint8_t *hm_mask = nullptr, *hm_records = nullptr, *hm_raw = nullptr;
@@ -513,6 +515,11 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
       h->hm_actions = (int32_t *)h->hm_block, h->hm_mask = h->hm_block + a, h->hm_records = h->hm_block + a + m, h->hm_raw = h->hm_block + a + m + r;
       h->hm_actions_d = (int32_t *)d, h->hm_mask_d = d + a, h->hm_records_d = d + a + m, h->hm_raw_d = d + a + m + r;
       h->fast_host = !getenv("SKYJO_NO_FAST_HOST");
+      h->host_spin = !getenv("SKYJO_NO_SPIN");
+      // Whole games come back with the records only for a few tiles (the single-game views: get_state / rewards after a step
+      // without device traffic).  At raw_stride ~ 400 B per game the export is per-lane 16-byte stores at that stride over
+      // PCIe - for a mid-size batch whose caller may never ask for a state that is dead weight.
+      h->raw_export = h->fast_host && P.tiles <= 4 && !getenv("SKYJO_NO_RAW_EXPORT");
     }
   }
   // The dealing kernel runs beside the step kernel (own stream) when the batch leaves SIMDs free: up to 768 tiles of
@@ -682,6 +689,7 @@ int skyjo_vec_snapshot_restore(skyjo_vec *h, const skyjo_vec_snapshot *sn, void 
   h->list_sel = sn->list_sel, h->auto_interval = sn->auto_interval, h->health_seen = sn->health_seen;
   h->deal_tag = sn->deal_tag, h->P.deal_tag = sn->deal_tag, h->iter = sn->iter, h->iters_total = sn->iters_total;
   h->health_host[0] = sn->health[0], h->health_host[1] = sn->health[1];
+  h->health_host[2] = 0;  // the restored device word is clean (snapshot_create refuses a voided run): so is the host's copy
   h->deal_inflight = false, h->inflight_piped = false;
   h->raw_valid = false;
   return SKYJO_OK;
@@ -1326,12 +1334,12 @@ int skyjo_vec_step_host(skyjo_vec *h, const int32_t *actions_host, void *records
     // A single tile is a single wavefront: it signs off with a sequence number in host-mapped memory as its very last
     // store, and the host spins on that word - a stream synchronisation costs ~10 us more than the kernel takes.  (The
     // stream stays ordered: whatever is launched next runs behind this kernel as usual.)
-    const bool spin = h->P.tiles == 1 && !getenv("SKYJO_NO_SPIN");
+    const bool spin = h->P.tiles == 1 && h->host_spin;
     if (spin) {
       h->host_seq = h->host_seq + 1 ? h->host_seq + 1 : 1;
       h->P.host_seq = h->host_seq;
     }
-    int rc = step_once(h, h->hm_actions_d, h->hm_records_d, nullptr, nullptr, nullptr, h->hm_raw_d);
+    int rc = step_once(h, h->hm_actions_d, h->hm_records_d, nullptr, nullptr, nullptr, h->raw_export ? h->hm_raw_d : nullptr);
     h->P.host_seq = 0;
     if (rc) return rc;
     bool arrived = false;
@@ -1340,7 +1348,7 @@ int skyjo_vec_step_host(skyjo_vec *h, const int32_t *actions_host, void *records
       for (long k = 0; k < 4000000 && !(arrived = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == h->host_seq); k++) __builtin_ia32_pause();
     }
     if (!arrived) HIPCHK(hipStreamSynchronize(nullptr));  // (also the fallback when the word does not come: ~0.1 s of spinning)
-    h->raw_valid = true;
+    h->raw_valid = h->raw_export;
     if (records_out_host) memcpy(records_out_host, h->hm_records, (size_t)h->P.B * h->P.L.rec_bytes);
     return dev_error_check(h);
   }
@@ -1381,10 +1389,10 @@ int skyjo_vec_reset_host(skyjo_vec *h, const uint8_t *mask_host, void *records_o
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   if (h->fast_host) {
     if (mask_host) memcpy(h->hm_mask, mask_host, (size_t)h->P.B);
-    int rc = reset_impl(h, mask_host ? h->hm_mask_d : nullptr, h->hm_records_d, nullptr, h->hm_raw_d);
+    int rc = reset_impl(h, mask_host ? h->hm_mask_d : nullptr, h->hm_records_d, nullptr, h->raw_export ? h->hm_raw_d : nullptr);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(nullptr));
-    h->raw_valid = true;
+    h->raw_valid = h->raw_export;
     if (records_out_host) memcpy(records_out_host, h->hm_records, (size_t)h->P.B * h->P.L.rec_bytes);
     return dev_error_check(h);
   }

@@ -547,6 +547,7 @@ __device__ __forceinline__ void reshuffle_dispatch(const SkParams &P, uint8_t *l
       if (w == SK_WAIT_TIMEOUT) {
         LB(H_FLAGS) |= F_DONE, LB(H_STATUS) = SKYJO_ST_ERROR, LB(H_NDRAW) = 1;
         P.done[g] = 1;
+        for (int q = 0; q < P.L.N; q++) P.rewards[(size_t)g * P.L.N + q] = 0.0;  // (an episode-end column must not pass stale values on)
         return;
       }
       undo_inflight = w == SK_WAIT_OK;
@@ -1082,7 +1083,8 @@ __device__ __forceinline__ constexpr int sk_stage_stride(int rec_bytes) { return
 // the game's current stream position.  Rare and slow (one lane active), never changes results.
 // When the game's stream cannot be had (wait_deal_done timed out: sticky device error) stream and bank stay untouched and
 // the slot is left as a finished game: it asks again in the next iteration.
-__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane, int head);
+// Returns false in that case: the caller must not present the slot as a freshly re-dealt game (status stays ERROR, no reset counted).
+__device__ __forceinline__ bool deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane, int head);
 
 // ------------------------------------------------------------------------------------------
 // k_step: `iters` lockstep iterations over all tiles.  POLICY=false: one iteration with the
@@ -1158,8 +1160,15 @@ __device__ __forceinline__ void sk_plan_deals(const SkParams &P, int g) {
 // no device traffic at all (skyjo_capi.hip: raw_valid).
 // The sticky device error (SK_ERR_*) goes to the host-mapped word that every synchronising host call looks at - written
 // by the kernels behind those calls (k_step with caller actions, k_reset, k_observe), not by the fused rollout kernel.
+// EVERY wavefront looks at the device's word on its way out (an atomic load: other CUs set it with atomicOr) and passes a
+// raised error on: the wavefront that raises one reaches its own end after the atomicOr, however long it spun - so the very
+// host call whose kernel timed out sees the error.  Kernels never clear the host's word (skyjo_vec_seed and
+// skyjo_vec_snapshot_restore do).
 __device__ __forceinline__ void sk_error_to_host(const SkParams &P) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) P.health_host[2] = *P.dev_error;
+  if (threadIdx.x == 0) {
+    const uint32_t e = __hip_atomic_load(P.dev_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (e) P.health_host[2] = e;
+  }
 }
 __device__ __forceinline__ void sk_export_raw(const SkParams &P, uint8_t *lp, int g, uint8_t *o) {
   for (int c = 0; c < P.L.chunks; c++) ((uint4 *)o)[c] = LQ(c);
@@ -1265,15 +1274,18 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
       } else if (!skip) {
         a = -1;
         if (P.auto_reset) {
+          bool dealt = true;
           if (!spare_commit(P, lp, g, sp)) {
 #ifndef SK_EXP_NO_RARE
-            deal_inline(P, lp, fp, g, tile, lane, sp.head);
+            dealt = deal_inline(P, lp, fp, g, tile, lane, sp.head);
 #endif
             cnt.waits++;  // counts the slow-path deals
           }
           HDR_LOAD(h);
-          h.w0 = (h.w0 & 0x00ffffffu) | ((uint32_t)SKYJO_ST_RESET << 24);
-          cnt.resets++;
+          if (SK_OFTEN(dealt)) {
+            h.w0 = (h.w0 & 0x00ffffffu) | ((uint32_t)SKYJO_ST_RESET << 24);
+            cnt.resets++;
+          }  // (else: the dealing launch never came - the record shows done / SKYJO_ST_ERROR, include/skyjo_vec.h)
         } else {
           h.w0 = (h.w0 & 0x00ffffffu) | ((uint32_t)SKYJO_ST_NOOP_DONE << 24);
         }
@@ -1485,11 +1497,14 @@ __global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *ma
   uint8_t *fp = (uint8_t *)lds_raw + P.L.chunks * 1024 + lane * 4;
   if (g >= P.B) return;
   const bool want = !mask || mask[g];
+  bool want_counted = false;  // (a reset whose deal timed out is not one)
   tile_load(P, P.state, tile, lane, lp);
   if (want) {
     const int head = P.bank_head[g] % SK_BANK;
-    if (!consume_spare(P, lp, tile, lane, g, head)) deal_inline(P, lp, fp, g, tile, lane, head);
-    LB(H_STATUS) = SKYJO_ST_RESET;
+    bool dealt = true;
+    if (!consume_spare(P, lp, tile, lane, g, head)) dealt = deal_inline(P, lp, fp, g, tile, lane, head);
+    if (dealt) LB(H_STATUS) = SKYJO_ST_RESET;
+    want_counted = dealt;
   }
   HdrRegs h;
   HDR_LOAD(h);
@@ -1501,8 +1516,8 @@ __global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *ma
   if (want) tile_store(P, P.state, tile, lane, lp);
   if (raw_out && (LB(H_FLAGS) & F_VALID)) sk_export_raw(P, lp, g, raw_out + (size_t)g * raw_stride);
   sk_error_to_host(P);
-  const unsigned long long wb = __ballot(want);
-  if (want && lane == __ffsll((long long)wb) - 1) P.tile_counters[(size_t)tile * 8 + 3] += __popcll(wb);
+  const unsigned long long wb = __ballot(want_counted);
+  if (want_counted && lane == __ffsll((long long)wb) - 1) P.tile_counters[(size_t)tile * 8 + 3] += __popcll(wb);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2022,7 +2037,7 @@ __device__ __forceinline__ void deal_into_lds(const SkParams &P, uint8_t *lp, Rn
   refresh_minima(P, lp);
 }
 
-__device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane, int head) {
+__device__ __forceinline__ bool deal_inline(const SkParams &P, uint8_t *lp, uint8_t *fp, int g, int tile, int lane, int head) {
   const uint32_t ep = P.deals_consumed[g];
   const int busy = P.busy[g];
   if (busy) {
@@ -2033,13 +2048,14 @@ __device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint
       const int w = wait_deal_done(P, g);
       if (w == SK_WAIT_TIMEOUT) {
         LB(H_FLAGS) = F_VALID | F_DONE, LB(H_STATUS) = SKYJO_ST_ERROR;
-        return;
+        for (int q = 0; q < P.L.N; q++) P.rewards[(size_t)g * P.L.N + q] = 0.0;  // (nothing stale for an episode-end column to pass on)
+        return false;
       }
       P.cancel[g] = 1;  // taken here: the publishing kernel must not mark the slot ready
       if (w == SK_WAIT_OK) {
         load_spare(P, lp, busy - 1, tile, lane);
         bank_advance(P, lp, g, head, ep);
-        return;
+        return true;
       }
     }  // Philox deals do not depend on a stream position (and a cancelled / overrun MT deal has finished): deal here
     P.cancel[g] = 1;  // superseded: the publishing kernel must not mark the slot ready
@@ -2057,6 +2073,7 @@ __device__ __forceinline__ void deal_inline(const SkParams &P, uint8_t *lp, uint
   LB(H_BANK) = (uint8_t)head;  // the bank is empty; its head pointer survives the new record
   P.deals_consumed[g] = ep + 1;
   P.done[g] = 0;
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------

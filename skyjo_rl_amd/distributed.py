@@ -37,6 +37,23 @@ def stats_record(counters, num_players):
     return rec
 
 
+def combine_stats(per_rank, num_players):
+    """Totals of the gathered records [W, F] (one row per rank, stats_record's layout): what every rank holds after the
+    all-gather.  Sums are taken in rank order, so the result does not depend on which rank computes it."""
+    allr = np.asarray(per_rank, dtype=np.float64)
+    tot = allr.sum(0)
+    totals = {k: tot[i] for i, k in enumerate(STAT_FIELDS)}
+    n = len(STAT_FIELDS)
+    for j, key in enumerate(SEAT_FIELDS):
+        totals[key] = tot[n + j * num_players:n + (j + 1) * num_players]
+    totals["mean_episode_len"] = totals["sum_len"] / max(totals["episodes"], 1.0)
+    ep = max(totals["episodes"] + totals["illegal"], 1.0)
+    totals["mean_reward"] = totals["sum_reward"] / ep                       # per seat, over finished + illegal episodes
+    totals["std_reward"] = np.sqrt(np.maximum(totals["sum_reward_sq"] / ep - totals["mean_reward"] ** 2, 0.0))
+    totals["mean_score"] = totals["sum_score"] / max(totals["episodes"], 1.0)
+    return totals
+
+
 def gather_stats(counters, num_players, device=None):
     """All-gather the per-rank statistics record; returns (per_rank [W, F] ndarray, totals dict)."""
     import torch
@@ -51,14 +68,4 @@ def gather_stats(counters, num_players, device=None):
         allr = torch.stack(out).cpu().numpy()
     else:
         allr = rec.cpu().numpy()[None]
-    tot = allr.sum(0)
-    totals = {k: tot[i] for i, k in enumerate(STAT_FIELDS)}
-    n = len(STAT_FIELDS)
-    for j, key in enumerate(SEAT_FIELDS):
-        totals[key] = tot[n + j * num_players:n + (j + 1) * num_players]
-    totals["mean_episode_len"] = totals["sum_len"] / max(totals["episodes"], 1.0)
-    ep = max(totals["episodes"] + totals["illegal"], 1.0)
-    totals["mean_reward"] = totals["sum_reward"] / ep                       # per seat, over finished + illegal episodes
-    totals["std_reward"] = np.sqrt(np.maximum(totals["sum_reward_sq"] / ep - totals["mean_reward"] ** 2, 0.0))
-    totals["mean_score"] = totals["sum_score"] / max(totals["episodes"], 1.0)
-    return allr, totals
+    return allr, combine_stats(allr, num_players)

@@ -27,6 +27,14 @@ the loops of rlskyjo/game/sample_game.py:5-28 and rlskyjo/environment/vanilla_en
 replay bit for bit (tests/golden/global_*.npz).  The default (``global_rng=False``) keeps one private
 stream per game, which is what a vector of games needs.
 
+CAVEAT - this is the reference's contract WITHOUT numba's JIT (``NUMBA_DISABLE_JIT=1``, the mode its seeded
+test pins, tests/environment/test_skyjo_env_jit.py:1-2, and the mode the golden fixtures were recorded in).
+With numba active - the reference's normal mode - ``np.random.*`` inside its ``@njit`` functions draws from
+numba's OWN generator, not from numpy's global stream, and the reference's ``set_seed`` docstring says it does
+not touch ``np.random.seed()`` of the caller.  ``global_rng=True`` here follows the no-JIT behaviour:
+``set_seed(v)`` calls ``np.random.seed(v + 1)`` on the CALLER's global stream (re-seeding it, unlike the jitted
+reference), and deals / reshuffles advance it.  Use the default private streams when that is not wanted.
+
 An *engine* is any object with the host-style methods of ``SkyjoVecEnv`` (seed, seed_one,
 reset_host, step_host, observe_host, rewards_host, get_state, set_state - and rng_set / rng_get /
 no_bank for the global-RNG mode); tests inject an oracle-backed one to check this file without a GPU.
