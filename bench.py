@@ -60,7 +60,37 @@ SETTLE = int(os.environ.get("SKYJO_BENCH_SETTLE", "100"))  # launches between se
 # build container (8-core Xeon 2.1 GHz); the reference cannot travel to the GPU box, so these are constants
 REFERENCE_STEPS_PER_S_1_CORE = 8.3e3
 REFERENCE_STEPS_PER_S_8_CORES = 52.8e3
-TRAFFIC_PROFILE = os.path.join("profiles", "r3_hbm_traffic.json")  # rocprofv3 PMC passes of this very launch shape (tools/refresh_profiles.sh)
+TRAFFIC_PROFILE = os.path.join("profiles", "r4_hbm_traffic.json")  # rocprofv3 PMC passes of this very launch shape (tools/refresh_profiles.sh)
+KERNEL_SOURCES = ("skyjo_rl_amd/csrc/skyjo_device.h", "skyjo_rl_amd/csrc/skyjo_capi.hip", "skyjo_rl_amd/csrc/skyjo_layout.h")
+
+
+def kernel_source_sha256():
+    """sha256 over the kernel sources: tools/collect_profiles.py stores it with the PMC traffic it digests, and the traffic
+    figure is only reported for the sources it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def committed_traffic(shape_ok):
+    """(k_step bytes per launch, k_deal fabric bytes per run, source note) from the committed PMC digest - or (None, None,
+    reason) when the digest is missing, was taken for another launch shape, or for other kernel sources than the ones built."""
+    tpath = os.path.join(ROOT, TRAFFIC_PROFILE)
+    if not shape_ok:
+        return None, None, "no PMC digest for this launch shape (the committed one: 65 536 x 3, MT19937, 64-byte records, 88 iterations)"
+    if not os.path.exists(tpath):
+        return None, None, f"{TRAFFIC_PROFILE} not found"
+    t = json.load(open(tpath))
+    if t.get("kernel_source_sha256") != kernel_source_sha256():
+        return None, None, (f"{TRAFFIC_PROFILE} was measured on other kernel sources (sha256 {str(t.get('kernel_source_sha256'))[:16]} != "
+                            f"{kernel_source_sha256()[:16]}): re-run tools/refresh_profiles.sh + tools/collect_profiles.py")
+    fab = t.get("k_deal_fabric") or {}
+    deal = fab.get("read_bytes", 0) + fab.get("write_bytes", 0) if fab else None
+    return t.get("k_step_bytes_per_launch"), deal, (f"{TRAFFIC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_* passes of this launch shape on these "
+                                                     f"kernel sources, tools/refresh_profiles.sh; not measured in this run)")
 
 
 def algorithmic_bytes_per_launch(B, N, D, iters, records=True):
@@ -172,7 +202,7 @@ def side_rollout_config(name, B, N, steps, warmup, device, rng_mode, indirect=Tr
            "iterations_per_launch": chunk, "timed_launches": steps, "dominant_kernel": "k_step",
            "dominant_kernel_ms": k_ms, "deal_kernel_ms": prof["deal_ms"] / max(prof["deal_launches"], 1),
            "roofline_frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
-           "dealing": "beside k_step" if eng.overlap() else "in line", "waits": int(c["waits"]),
+           "dealing": eng.dealing_form(), "waits": int(c["waits"]),
            "mean_episode_len": c["sum_len"] / max(c["episodes"], 1)}
     eng.close()
     return out
@@ -256,6 +286,8 @@ def main():
     ap.add_argument("--config", type=int, choices=[3, 4], default=3,
                     help="3: 65 536 games per GPU (BASELINE configs[2], weak scaling); 4: 32 768 per GPU (configs[3]: 262 144 at --gpus 8)")
     ap.add_argument("--num-envs", type=int, default=None, help="games per GPU (overrides --config)")
+    ap.add_argument("--total-games", type=int, default=None,
+                    help="STRONG scaling: this many games in total, G / N per GPU (default: weak scaling, --config's games on every GPU)")
     ap.add_argument("--num-players", type=int, default=3)
     ap.add_argument("--rng", choices=["mt19937", "philox"], default="mt19937")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -295,7 +327,12 @@ def main():
     torch.cuda.set_device(device)
     dev = torch.device("cuda", device)
 
-    B = args.num_envs if args.num_envs else (65536 if args.config == 3 else 32768)
+    strong = args.total_games is not None
+    if strong:
+        assert args.num_envs is None and args.total_games % world == 0, "--total-games must be a multiple of --gpus (and excludes --num-envs)"
+        B = args.total_games // world
+    else:
+        B = args.num_envs if args.num_envs else (65536 if args.config == 3 else 32768)
     N = args.num_players
     # shards by global game id (rank r owns games r*B .. (r+1)*B - 1): results do not depend on the GPU count
     eng = make_sharded_env(world * B, rank, world, num_players=N, observe_other_player_indirect=not args.direct_obs, device=device,
@@ -343,6 +380,9 @@ def main():
         # over RCCL (device tensors; gloo when ranks share a card)
         c1["wall"] = dt
         per_rank, tot = gather_stats(c1, N, device=dev)
+        # a silent single-rank fallback must be impossible: the gathered matrix has one row per rank, every row a full shard
+        assert per_rank.shape[0] == world, f"gathered {per_rank.shape[0]} statistics records for {world} ranks"
+        assert all(per_rank[r, 0] + per_rank[r, 3] == args.steps * CHUNK * B for r in range(world)), "a rank's steps + resets are not its shard's"
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -366,13 +406,10 @@ def main():
     avg_ms = prof["step_ms"] / max(full, 1)
     alg = algorithmic_bytes_per_launch(B, N, D, CHUNK, records=record) + (4 * B * CHUNK if act is not None else 0)
     achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, TRAFFIC_PROFILE)
-    if os.path.exists(tpath) and B == 65536 and N == 3 and record and act is None and CHUNK == 88 and not args.direct_obs and args.rng == "mt19937":
-        # NOT measured in this run: PMC counters need rocprofv3 around the process.  The figure is the committed profile of this
-        # very launch shape; `traffic_source` says so.
-        traffic = json.load(open(tpath)).get("k_step_bytes_per_launch")
-        traffic_source = f"{TRAFFIC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch shape, collected by tools/refresh_profiles.sh; not measured in this run)"
+    # NOT measured in this run: PMC counters need rocprofv3 around the process.  The figure is the committed digest of this very
+    # launch shape, and only if it was taken on the kernel sources that are built here (sha256 stored with it).
+    traffic, deal_traffic, traffic_source = committed_traffic(
+        B == 65536 and N == 3 and record and act is None and CHUNK == 88 and not args.direct_obs and args.rng == "mt19937")
     kernel_ms = {k: prof[k + "_ms"] / 32.0 for k in ("k_step", "k_scan", "k_deal", "k_publish")}  # per bench step (= per dealing cycle)
     path_ms = sum(kernel_ms.values())
     wall_ms = 1e3 * t_max / args.steps
@@ -383,10 +420,17 @@ def main():
 
     if rank == 0:
         vals = [b["value"] for b in blocks]
-        if args.num_envs is None and args.config == 4:
+        if strong:
+            scaling_note = f"strong: {args.total_games} games in total, {B} per GPU"
+        elif args.num_envs is None and args.config == 4:
             scaling_note = f"BASELINE configs[3]: 32 768 games per GPU ({world * B} in total; 262 144 at --gpus 8)"
         else:
             scaling_note = f"weak: {B} games per GPU ({world * B} in total)"
+        backend = dist.get_backend() if world > 1 else "none (single rank)"
+        try:
+            nccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())  # RCCL's version on ROCm
+        except Exception as e:  # (reported, not needed by a single rank)
+            nccl_version = f"unavailable: {e!r}"
         out = {
             "metric": "env-steps/sec (whole node) at 65 536 parallel 3-player games",
             "value": med["value"],
@@ -396,7 +440,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": wall_ms,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "int8",
             "data": "synthetic",
@@ -405,12 +449,15 @@ def main():
                                    f"record (obs + mask + applied action) written every step; one bench step = one fused launch of {CHUNK} lockstep iterations + its dealing run"
                                    if record else f"{B} x {N}-player games per GPU, no records",
                        "baseline_config": args.config if args.num_envs is None else None,
-                       "games_per_gpu": B, "num_players": N, "rng_mode": args.rng,
+                       "games_per_gpu": B, "games_total": world * B, "scaling_mode": "strong (--total-games)" if strong else "weak (per-GPU batch fixed)",
+                       "num_players": N, "rng_mode": args.rng,
+                       "collective": {"backend": backend, "rccl_version": nccl_version, "ranks_gathered": int(per_rank.shape[0]),
+                                      "world_size": world, "op": "all_gather of one float64 statistics record per rank and timed block"},
                        "iterations_per_step": CHUNK, "timed_iterations_per_block": args.steps * CHUNK, "warmup_iterations": args.warmup * CHUNK,
                        "settle_launches_before_warmup": SETTLE,
-                       "dealing": ("beside k_step (own stream; k_scan + k_publish)" if os.environ.get("SKYJO_PIPELINED") == "0" else
-                                   "beside k_step (own stream; planned and published by k_step itself)") if eng.overlap() else
-                                  ("in line (k_scan + k_deal)" if os.environ.get("SKYJO_FUSED_SCAN") == "0" else "in line (k_deal scans the banks itself)"),
+                       "dealing": {"one kernel": "one kernel per dealing cycle (k_cycle): one step + one dealing wavefront per SIMD, hand-over inside the CU",
+                                   "two streams": "beside k_step (own stream; planned and published by k_step itself)",
+                                   "in line": "in line (k_deal scans the banks itself)"}[eng.dealing_form()],
                        "shared_gpu_rehearsal": shared_gpu,
                        "parallelism": f"{scaling_note}; games sharded over {world} GPU(s) by global game id, no data-path collective; "
                                       f"one all-gather of the statistics record ({'gloo: ranks share a card' if shared_gpu else 'RCCL' if world > 1 else 'single rank'})"},
@@ -427,7 +474,8 @@ def main():
                               "refunded_per_episode": float(tot["sum_refunded"].sum() / max(episodes, 1.0))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": f"k_step<{'indirect' if not args.direct_obs else 'direct'},policy,{N if N in (2, 3, 4) else 0}>", "avg_launch_ms": avg_ms,
+                         "kernel": (f"k_cycle<indirect,{N}> (step + dealing wavefronts of one dealing cycle)" if eng.dealing_form() == "one kernel" else
+                                    f"k_step<{'indirect' if not args.direct_obs else 'direct'},policy,{N if N in (2, 3, 4) else 0}>"), "avg_launch_ms": avg_ms,
                          "launches_timed": full, "algorithmic_bytes_per_launch": alg,
                          "deal_kernel_avg_ms": prof["deal_ms"] / max(prof["deal_launches"], 1)},
             "roofline_path": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
@@ -435,6 +483,9 @@ def main():
                               "achieved_kernel_time": alg / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0,
                               "frac_kernel_time": alg / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if path_ms > 0 else 0.0,
                               "wall_ms_per_step": wall_ms,
+                              "traffic": (traffic + deal_traffic) if traffic is not None and deal_traffic is not None else None,
+                              "traffic_k_deal_fabric": deal_traffic, "traffic_source": traffic_source,
+                              "traffic_over_algorithmic": (traffic + deal_traffic) / alg if traffic is not None and deal_traffic is not None else None,
                               "achieved_wall": alg / (wall_ms * 1e-3) / 1e9,
                               "frac_wall": alg / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "k_deal": {"deals_per_step": deals_per_step, "rng_outputs_per_deal": rng_outputs_per_deal(N) if args.rng == "mt19937" else None,

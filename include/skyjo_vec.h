@@ -230,6 +230,9 @@ int skyjo_vec_snapshot_destroy(skyjo_vec_snapshot *snap);
 /* Diagnostic builds only (-DSK_STAMPS): per-section shader-cycle sums, 8 for the step kernel followed by 8 for
  * the dealing kernel, summed over wavefronts, cleared on read.  The shipped build returns zeros. */
 int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
+/* Diagnostic builds (-DSK_TRACE) only: placement and time span of every wavefront of the last two step / dealing launches,
+ * uint64 [4][tiles][8] (tools/dev/placement.py).  Zeros in the shipped build. */
+int skyjo_vec_debug_trace(skyjo_vec *h, uint64_t *out_host);
 
 /* Tunables.  SKYJO_OPT_DEAL_INTERVAL: lockstep iterations (steps or rollout iterations) between two runs of the
  * dealing kernel (1..1024; environment override SKYJO_DEAL_INTERVAL).  Unless it is set, the engine starts at 88 (three
@@ -238,11 +241,18 @@ int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
  * pre-dealt episodes and a dealing run adds at most one per game; a finished game whose bank is empty deals in
  * place (slow path, same result, counted in skyjo_vec_counters.waits). */
 #define SKYJO_OPT_DEAL_INTERVAL 1
-/* SKYJO_OPT_OVERLAP: 1 = the dealing kernel runs on a stream of its own beside the step kernels that follow it
- * (its episodes are published one dealing cycle later; the step kernel plans and publishes the runs itself, nothing on the
- * caller's stream waits for the dealing stream), 0 = it runs in line on the caller's stream.  Default: 1 when
- * the batch leaves SIMDs idle (at most 768 tiles of 64 games), 0 on a full chip; environment override SKYJO_OVERLAP.
- * Results do not depend on this setting. */
+/* SKYJO_OPT_OVERLAP - where the dealing runs (results do not depend on it):
+ *   0  in line on the caller's stream, after the step launch that makes it due;
+ *   2  the two-stream form: the dealing kernel on a stream of its own beside the step kernels that follow (its episodes are
+ *      published one dealing cycle later; the step kernel plans and publishes the runs itself, nothing on the caller's
+ *      stream waits for the dealing stream).  Default for batches that leave SIMDs idle (at most 768 tiles of 64 games);
+ *   3  the one-kernel form (k_cycle): every workgroup is one CU's worth of wavefronts, one step and one dealing wavefront per
+ *      SIMD, the dealing wavefronts work for the games of their own workgroup - the hand-over never leaves the CU, so it needs
+ *      no L2 write-back / invalidation.  Two to four players, indirect observation; S = 1 .. 4 step and as many dealing wavefronts
+ *      per workgroup, whichever spreads the batch over the CUs (their LDS regions must fit 160 KB: four players up to S = 3).
+ *      Default on a full chip (more than 768 tiles); the fused rollout only - other calls deal as in form 0;
+ *   1  "beside the step kernel" in whichever of the two forms the engine prefers.
+ * skyjo_vec_get_option returns 0, 2 or 3.  Environment overrides: SKYJO_OVERLAP (0 / 1), SKYJO_MERGED (0 / 1: prefer form 3). */
 #define SKYJO_OPT_OVERLAP 2
 /* Fault injection for the tests (never needed in production): SKYJO_OPT_DEBUG_SPIN_LOG2 - a step kernel that has to wait
  * for an overlapped dealing kernel gives up after 2^value polls (default 22) and raises the sticky device error that
@@ -344,6 +354,18 @@ int skyjo_vec_observe_host(skyjo_vec *h, const int32_t *players_host, void *reco
 int skyjo_vec_reset_host(skyjo_vec *h, const uint8_t *mask_host, void *records_out_host);
 int skyjo_vec_get_rewards_host(skyjo_vec *h, double *rewards_out_host, double *scores_out_host,
                                uint8_t *done_out_host);
+
+/* The reference's two scoring helpers for CALLER-SUPPLIED hands (its notebook calls them directly; inside a game the step
+ * kernel computes the same).  Host pointers, computed on device `device_id`, synchronous; float64 in numpy's operation order.
+ *   skyjo_vec_evaluate_game       SkyjoGame._evaluate_game(players_cards, player_won_id, score_penalty)  (skyjo.py:477-498):
+ *                             players_cards int8[n][num_players][12], player_won_id int32[n] -> scores double[n][num_players]
+ *   skyjo_vec_calc_final_rewards  SimpleSkyjoEnv._calc_final_rewards(final_score, num_refunded)          (skyjo_env.py:293-312):
+ *                             final_score double[n][num_players], num_refunded int32[n][num_players] -> rewards double[n][num_players] */
+int skyjo_vec_evaluate_game(int32_t device_id, int32_t n, int32_t num_players, const int8_t *players_cards_host,
+                        const int32_t *player_won_id_host, double score_penalty, double *scores_out_host);
+int skyjo_vec_calc_final_rewards(int32_t device_id, int32_t n, int32_t num_players, const double *final_score_host,
+                             const int32_t *num_refunded_host, double mean_reward, double reward_refunded,
+                             double *rewards_out_host);
 
 /* plain device-memory helpers so that a caller without torch can own buffers */
 int skyjo_dev_malloc(int device_id, size_t bytes, void **out);

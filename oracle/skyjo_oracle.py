@@ -11,6 +11,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libskyjo_oracle.so")
+# SKYJO_ORACLE_SANITIZE=1: the AddressSanitizer + UBSan build (`make -C oracle asan`); the interpreter must then run with
+# LD_PRELOAD=$(gcc -print-file-name=libasan.so) - `make -C oracle check-asan` does both
+_SANITIZE = os.environ.get("SKYJO_ORACLE_SANITIZE") == "1"
+if _SANITIZE:
+    _SO = os.path.join(_HERE, "_build", "libskyjo_oracle_asan.so")
 
 ST_OK, ST_ILLEGAL, ST_NOOP_DONE, ST_RESET = 0, 1, 2, 3
 RNG_MT19937, RNG_PHILOX = 0, 1
@@ -23,7 +28,7 @@ def build(force=False):
     if force or not os.path.exists(_SO) or any(
             os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         if all(os.path.exists(s) for s in src):
-            subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
+            subprocess.check_call(["make", "-C", _HERE, "-s"] + (["asan"] if _SANITIZE else []), stdout=subprocess.DEVNULL)
     return _SO
 
 

@@ -113,12 +113,15 @@ SIGNATURES = {
     "skyjo_vec_snapshot_bytes": (C.c_int, [VP, C.POINTER(C.c_size_t)]),
     "skyjo_vec_snapshot_destroy": (C.c_int, [VP]),
     "skyjo_vec_debug_stamps": (C.c_int, [VP, VP]),
+    "skyjo_vec_debug_trace": (C.c_int, [VP, VP]),
     "skyjo_vec_set_option": (C.c_int, [VP, C.c_int, I64]),
     "skyjo_vec_get_option": (C.c_int, [VP, C.c_int, C.POINTER(I64)]),
     "skyjo_vec_step_host": (C.c_int, [VP, VP, VP]),
     "skyjo_vec_observe_host": (C.c_int, [VP, VP, VP]),
     "skyjo_vec_reset_host": (C.c_int, [VP, VP, VP]),
     "skyjo_vec_get_rewards_host": (C.c_int, [VP, VP, VP, VP]),
+    "skyjo_vec_evaluate_game": (C.c_int, [I32, I32, I32, VP, VP, C.c_double, VP]),
+    "skyjo_vec_calc_final_rewards": (C.c_int, [I32, I32, I32, VP, VP, C.c_double, C.c_double, VP]),
     "skyjo_dev_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(VP)]),
     "skyjo_dev_free": (C.c_int, [VP]),
     "skyjo_dev_copy": (C.c_int, [VP, VP, C.c_size_t, C.c_int, VP]),

@@ -259,6 +259,24 @@ class SimpleSkyjoEnv:
         rewards, _, _ = self._engine.rewards_host()
         return np.array(rewards[0], dtype=np.float64)
 
+    def _calc_final_rewards(self, final_score, num_refunded, **kwargs):
+        """``SimpleSkyjoEnv._calc_final_rewards`` (skyjo_env.py:293-312) for caller-supplied results: reward relative to the
+        mean score, + ``mean_reward``, + ``reward_refunded`` per refunded column.  Computed on the device
+        (``skyjo_vec_calc_final_rewards``), float64 in numpy's operation order."""
+        import ctypes as C
+
+        from . import _lib
+
+        score = np.ascontiguousarray(final_score, dtype=np.float64).ravel()
+        ref = np.ascontiguousarray(num_refunded, dtype=np.int32).ravel()
+        assert score.shape == ref.shape and 0 < score.shape[0] <= 12
+        out = np.zeros_like(score)
+        dev = getattr(self._engine, "device_index", 0)
+        _lib.check(_lib.load().skyjo_vec_calc_final_rewards(int(dev), 1, int(score.shape[0]), score.ctypes.data_as(C.c_void_p),
+                                                        ref.ctypes.data_as(C.c_void_p), float(self.mean_reward),
+                                                        float(self.reward_refunded), out.ctypes.data_as(C.c_void_p)))
+        return out
+
     @staticmethod
     def _name_to_player_id(name: str) -> int:
         return int(name.split("_")[-1])

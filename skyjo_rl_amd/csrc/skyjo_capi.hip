@@ -94,6 +94,13 @@ struct skyjo_vec {
   hipEvent_t ev_scan = nullptr, ev_dealt = nullptr;
   bool deal_inflight = false;
   bool piped = true;           // beside the step kernel: the step kernel plans / publishes the runs itself (SKYJO_PIPELINED=0: k_scan + k_publish)
+  // Full-chip batches of two / three players (indirect observation): ONE kernel per dealing cycle, k_cycle - eight wavefronts per
+  // CU, the four on SIMDs 0 / 2 step, the four on SIMDs 1 / 3 deal the run the previous launch planned (the pipelined protocol,
+  // no second stream).  cycle_deal_tag != 0: a planned run waits for the next launch to carry it.
+  bool merged = false, merged_capable = false, prefer_merged = false;
+  uint32_t cycle_deal_tag = 0;
+  size_t lds_cycle = 0;
+  int cycle_s = SK_CYCLE_MAX_S;  // step (= dealing) wavefronts per workgroup of k_cycle
   bool inflight_piped = false; // the run(s) in flight were planned that way
   int list_sel = 0;
   uint32_t deal_tag = 0;  // k_step launches between two k_deal launches inside skyjo_vec_rollout
@@ -201,9 +208,24 @@ int prof_events(skyjo_vec *h, int kernel, hipEvent_t *a, hipEvent_t *b) {
 }
 
 // Make the episodes of the dealing launch that may still be running available (k_publish on the caller's stream).
+static int launch_deal_kernel(skyjo_vec *h, hipStream_t ds, int mode);
+// k_cycle form: a run that was planned but whose carrying launch never came (the caller went on with another kind of call) is
+// dealt here, by the dealing kernel alone on the caller's stream.
+int flush_cycle_deal(skyjo_vec *h, hipStream_t s) {
+  if (!h->cycle_deal_tag) return SKYJO_OK;
+  const uint32_t keep = h->P.deal_tag;
+  h->P.deal_tag = h->cycle_deal_tag;
+  h->cycle_deal_tag = 0;
+  const int rc = launch_deal_kernel(h, s, 3);
+  h->P.deal_tag = keep;
+  return rc;
+}
+
 int publish_deals(skyjo_vec *h, hipStream_t s) {
+  int rcf = flush_cycle_deal(h, s);
+  if (rcf) return rcf;
   if (!h->deal_inflight) return SKYJO_OK;
-  if (h->overlap) HIPCHK(hipStreamWaitEvent(s, h->ev_dealt, 0));
+  if (h->overlap && !h->merged) HIPCHK(hipStreamWaitEvent(s, h->ev_dealt, 0));
   hipEvent_t e0, e1;
   int rc = prof_events(h, 3, &e0, &e1);
   if (rc) return rc;
@@ -220,7 +242,7 @@ int publish_deals(skyjo_vec *h, hipStream_t s) {
 
 // mode: 0 = work list, beside the step kernel (k_publish follows); 1 = work list, in line; 2 = in line, lane = game, own
 // scan; 3 = beside the step kernel, lane = game, planned by the step kernel (sk_plan_deals)
-static int launch_deal_kernel(skyjo_vec *h, hipStream_t ds, int mode) {
+int launch_deal_kernel(skyjo_vec *h, hipStream_t ds, int mode) {
   hipEvent_t e0, e1;
   int rc;
   if ((rc = prof_events(h, 2, &e0, &e1))) return rc;
@@ -306,7 +328,7 @@ int start_deals(skyjo_vec *h, hipStream_t s) {
 // The pipelined form of a dealing cycle beside the step kernel (skyjo_device.h, sk_plan_deals): plan_cycle() before the
 // step launch after which the run is due - that launch plans the run on its way out -, start_deals_piped() after it:
 // the dealing kernel goes to its own stream behind an event for that launch.  Nothing on the caller's stream waits.
-static bool piped_mode(const skyjo_vec *h) { return h->overlap && h->piped && !h->no_bank; }
+static bool piped_mode(const skyjo_vec *h) { return ((h->overlap && h->piped) || h->merged) && !h->no_bank; }
 static void plan_cycle(skyjo_vec *h) {
   next_deal_tag(h, false);
   h->P.plan_new_tag = h->deal_tag;
@@ -314,6 +336,14 @@ static void plan_cycle(skyjo_vec *h) {
 }
 int start_deals_piped(skyjo_vec *h, hipStream_t s) {
   int rc;
+  if (h->merged) {  // the next k_cycle launch carries the run (its wavefronts on SIMDs 1 / 3); nothing is launched here
+    if ((rc = flush_cycle_deal(h, s))) return rc;  // (an older run that no launch has carried yet: deal it now)
+    h->cycle_deal_tag = h->deal_tag;
+    h->deal_inflight = true, h->inflight_piped = true;
+    h->pending_iters = 0;
+    adapt_interval(h);
+    return SKYJO_OK;
+  }
   HIPCHK(hipEventRecord(h->ev_scan, s));
   HIPCHK(hipStreamWaitEvent(h->deal_stream, h->ev_scan, 0));
   if ((rc = launch_deal_kernel(h, h->deal_stream, 3))) return rc;
@@ -333,6 +363,30 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
   hipEvent_t e0, e1;
   if ((rc = prof_events(h, 0, &e0, &e1))) return rc;
   if (h->deal_inflight && h->inflight_piped) h->P.ov_flags |= 1u;  // publish what has been dealt since (sk_publish_deals)
+  if (h->merged && policy && ind && !end_rew && !raw_out) {
+    // one kernel for the whole dealing cycle: S step + S dealing wavefronts per workgroup (= per CU)
+    uint32_t lds_deal = SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE), tag = h->cycle_deal_tag;
+    h->cycle_deal_tag = 0;
+    if (const char *e = getenv("SKYJO_CYCLE_SPLIT")) lds_deal |= (uint32_t)(atoi(e) & 3) << 30;  // diagnostic: 1 = roles by SIMD parity, 2 = by SIMD pair
+    const int S = h->cycle_s;
+    dim3 cgrid((h->P.tiles + S - 1) / S), cblock(2 * S * SK_TILE);
+#define LAUNCHC(NP)                                                                                                                       \
+  hipExtLaunchKernelGGL((k_cycle<true, NP>), cgrid, cblock, (uint32_t)h->lds_cycle, s, e0, e1, 0, h->P, rec, act_out, iters, policy_seed, \
+                        h->iter, tag, (uint32_t)h->lds_rollout, lds_deal)
+    switch (h->P.L.N) {
+      case 2: LAUNCHC(2); break;
+      case 3: LAUNCHC(3); break;
+      default: LAUNCHC(4); break;
+    }
+#undef LAUNCHC
+    HIPCHK(hipGetLastError());
+    h->P.ov_flags = 0;
+    h->iters_total += (uint64_t)iters;
+    h->iter += (uint64_t)iters;
+    h->pending_iters += iters;
+    return SKYJO_OK;
+  }
+  if ((rc = flush_cycle_deal(h, s))) return rc;  // (another kind of step: a planned run does not wait for a k_cycle launch)
 #define LAUNCH3(I, Pol, NP)                                                                                       \
   hipExtLaunchKernelGGL((k_step<I, Pol, NP>), grid, block, (uint32_t)(Pol ? h->lds_rollout : h->lds_step), s, e0, e1, 0, h->P, actions,   \
                         rec, act_out, iters, policy_seed, h->iter, end_rew, end_flag, raw_out, h->raw_stride)
@@ -461,7 +515,7 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
         (rc = dalloc(h, &P.deals_consumed, h->G)) || (rc = dalloc(h, &P.rewards, h->G * N)) ||
         (rc = dalloc(h, &P.scores, h->G * N)) || (rc = dalloc(h, &P.done, h->G)) ||
         (rc = dalloc(h, &P.acc_tile, (size_t)P.tiles * SK_ACC_KINDS * SKYJO_MAX_PLAYERS)) || (rc = dalloc(h, &P.dev_error, 1)) ||
-        (rc = dalloc(h, &P.counters, 1)) || (rc = dalloc(h, &P.tile_counters, (size_t)P.tiles * 8)) || (rc = dalloc(h, &P.stamps, (size_t)P.tiles * 16))) {
+        (rc = dalloc(h, &P.counters, 1)) || (rc = dalloc(h, &P.tile_counters, (size_t)P.tiles * 8)) || (rc = dalloc(h, &P.stamps, (size_t)P.tiles * 32))) {
       return rc;
     }
     return SKYJO_OK;
@@ -528,9 +582,34 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   // vector ALUs), in line above that.  SKYJO_OPT_OVERLAP / SKYJO_OVERLAP override.
   h->overlap = P.tiles <= 768;
   if (const char *e = getenv("SKYJO_OVERLAP")) h->overlap = atoi(e) != 0;
+  {
+    // k_cycle: S step + S dealing wavefronts per workgroup, S = what spreads the batch over the 256 CUs (1 .. 4); their LDS
+    // regions and the claim words must fit one CU's 160 KB
+    const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int S = (P.tiles + ncu - 1) / ncu;
+    S = S < 1 ? 1 : (S > SK_CYCLE_MAX_S ? SK_CYCLE_MAX_S : S);
+    if (const char *e = getenv("SKYJO_CYCLE_S")) S = atoi(e) >= 1 && atoi(e) <= SK_CYCLE_MAX_S ? atoi(e) : S;
+    const size_t need = (size_t)S * (h->lds_rollout + (size_t)SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE)) + 32;
+    const bool fits = fixed_n && P.L.indirect && need <= 160 * 1024 && !getenv("SKYJO_LDS_PAD");
+    h->lds_cycle = need, h->cycle_s = S;
+    h->merged_capable = fits;
+    if (fits) {
+      const void *fn = cfg->num_players == 2 ? (const void *)k_cycle<true, 2> : cfg->num_players == 3 ? (const void *)k_cycle<true, 3> : (const void *)k_cycle<true, 4>;
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) {
+        (void)hipGetLastError();
+        h->merged_capable = false;
+      }
+    }
+    // Default: the one-kernel form wherever it fits (measured at 4 096 .. 65 536 games and two to four players: + 9 .. 32 % over the
+    // two-stream form, + 18 .. 57 % over dealing in line, EXPERIMENTS.md round 4); SKYJO_MERGED=0 falls back to the older forms.
+    h->prefer_merged = true;
+    if (const char *e = getenv("SKYJO_MERGED")) h->prefer_merged = atoi(e) != 0;
+    h->merged = h->merged_capable && h->prefer_merged && !getenv("SKYJO_OVERLAP");
+    if (h->merged) h->overlap = false;  // (no second stream in this form)
+  }
   if (const char *e = getenv("SKYJO_FUSED_SCAN")) h->fused_scan = atoi(e) != 0;
   if (const char *e = getenv("SKYJO_PIPELINED")) h->piped = atoi(e) != 0;
-  h->deal_every_iters = h->interval_default = deal_interval_default(cfg->num_players, h->overlap, h->piped);
+  h->deal_every_iters = h->interval_default = deal_interval_default(cfg->num_players, h->overlap || h->merged, h->piped || h->merged);
   if (const char *e = getenv("SKYJO_DEAL_INTERVAL")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 1024) h->deal_every_iters = v, h->auto_interval = false;
@@ -1272,11 +1351,19 @@ int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host) {
   return SKYJO_OK;
 }
 
+int skyjo_vec_debug_trace(skyjo_vec *h, uint64_t *out_host) {  // [4][tiles][8]: see TRACE_STORE (skyjo_device.h); zeros unless built with -DSK_TRACE
+  if (!h || !out_host) return fail(SKYJO_E_INVALID, "null argument");
+  GUARD(h);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out_host, h->P.stamps, (size_t)h->P.tiles * 32 * 8, hipMemcpyDeviceToHost));
+  return SKYJO_OK;
+}
+
 int skyjo_vec_get_option(const skyjo_vec *h, int option, int64_t *value_out) {
   if (!h || !value_out) return fail(SKYJO_E_INVALID, "null argument");
   switch (option) {
     case SKYJO_OPT_DEAL_INTERVAL: *value_out = h->deal_every_iters; return SKYJO_OK;
-    case SKYJO_OPT_OVERLAP: *value_out = h->overlap ? 1 : 0; return SKYJO_OK;
+    case SKYJO_OPT_OVERLAP: *value_out = h->merged ? 3 : h->overlap ? 2 : 0; return SKYJO_OK;
     case SKYJO_OPT_NO_BANK: *value_out = h->no_bank ? 1 : 0; return SKYJO_OK;
     default: return fail(SKYJO_E_INVALID, "unknown option");
   }
@@ -1294,8 +1381,13 @@ int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
       int rc = publish_deals(h, nullptr);  // drain the pipeline before changing its shape
       if (rc) return rc;
       HIPCHK(hipDeviceSynchronize());
-      h->overlap = value != 0;
-      h->interval_default = deal_interval_default(h->P.L.N, h->overlap, h->piped);
+      // 0: in line; 1: beside the step kernel, in the form this engine prefers; 2: the two-stream form; 3: the one-kernel form (k_cycle)
+      if (value < 0 || value > 3) return fail(SKYJO_E_INVALID, "SKYJO_OPT_OVERLAP takes 0 .. 3");
+      if (value == 3 && !h->merged_capable)
+        return fail(SKYJO_E_INVALID, "the one-kernel form needs two to four players, the indirect observation and its workgroup's LDS regions within 160 KB");
+      h->merged = value == 3 || (value == 1 && h->merged_capable && h->prefer_merged);
+      h->overlap = value != 0 && !h->merged;
+      h->interval_default = deal_interval_default(h->P.L.N, h->overlap || h->merged, h->piped || h->merged);
       if (h->auto_interval) h->deal_every_iters = h->interval_default;
       return SKYJO_OK;
     }
@@ -1437,6 +1529,69 @@ int skyjo_dev_free(void *p) {
   if (p) HIPCHK(hipFree(p));
   return SKYJO_OK;
 }
+// ---- the reference's scoring helpers for caller-supplied hands (host pointers; computed on the device) ----
+namespace {
+struct DevBuf {  // a scratch allocation that frees itself
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+int score_device(int32_t device_id, int *ndev_out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SKYJO_E_NOGPU, "no HIP device visible: this library has no CPU fallback");
+  if (device_id < 0 || device_id >= ndev) return fail(SKYJO_E_INVALID, "device_id out of range");
+  *ndev_out = ndev;
+  return SKYJO_OK;
+}
+}  // namespace
+
+int skyjo_vec_evaluate_game(int32_t device_id, int32_t n, int32_t num_players, const int8_t *players_cards_host, const int32_t *player_won_id_host,
+                        double score_penalty, double *scores_out_host) {
+  if (!players_cards_host || !player_won_id_host || !scores_out_host || n < 0) return fail(SKYJO_E_INVALID, "skyjo_vec_evaluate_game: bad argument");
+  if (num_players <= 0 || num_players > SKYJO_MAX_PLAYERS) return fail(SKYJO_E_INVALID, "skyjo_vec_evaluate_game: num_players must be 1..12");
+  for (int32_t i = 0; i < n; i++)
+    if (player_won_id_host[i] < 0 || player_won_id_host[i] >= num_players) return fail(SKYJO_E_INVALID, "skyjo_vec_evaluate_game: player_won_id out of range");
+  int ndev, rc;
+  if ((rc = score_device(device_id, &ndev))) return rc;
+  if (n == 0) return SKYJO_OK;
+  DevGuard guard_(device_id);
+  const size_t cb = (size_t)n * num_players * 12, wb = (size_t)n * 4, sb = (size_t)n * num_players * 8;
+  const size_t o_w = (cb + 255) & ~(size_t)255, o_s = o_w + ((wb + 255) & ~(size_t)255);
+  DevBuf d;
+  HIPCHK(hipMalloc(&d.p, o_s + sb));
+  uint8_t *b = (uint8_t *)d.p;
+  HIPCHK(hipMemcpy(b, players_cards_host, cb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b + o_w, player_won_id_host, wb, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_evaluate_game, dim3((n + 63) / 64), dim3(64), 0, nullptr, (int)n, (int)num_players, (const int8_t *)b, (const int32_t *)(b + o_w),
+                     score_penalty, (double *)(b + o_s));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(scores_out_host, b + o_s, sb, hipMemcpyDeviceToHost));
+  return SKYJO_OK;
+}
+
+int skyjo_vec_calc_final_rewards(int32_t device_id, int32_t n, int32_t num_players, const double *final_score_host, const int32_t *num_refunded_host,
+                             double mean_reward, double reward_refunded, double *rewards_out_host) {
+  if (!final_score_host || !num_refunded_host || !rewards_out_host || n < 0) return fail(SKYJO_E_INVALID, "skyjo_vec_calc_final_rewards: bad argument");
+  if (num_players <= 0 || num_players > SKYJO_MAX_PLAYERS) return fail(SKYJO_E_INVALID, "skyjo_vec_calc_final_rewards: num_players must be 1..12");
+  int ndev, rc;
+  if ((rc = score_device(device_id, &ndev))) return rc;
+  if (n == 0) return SKYJO_OK;
+  DevGuard guard_(device_id);
+  const size_t sb = (size_t)n * num_players * 8, fb = (size_t)n * num_players * 4;
+  const size_t o_f = (sb + 255) & ~(size_t)255, o_r = o_f + ((fb + 255) & ~(size_t)255);
+  DevBuf d;
+  HIPCHK(hipMalloc(&d.p, o_r + sb));
+  uint8_t *b = (uint8_t *)d.p;
+  HIPCHK(hipMemcpy(b, final_score_host, sb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b + o_f, num_refunded_host, fb, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_final_rewards, dim3((n + 63) / 64), dim3(64), 0, nullptr, (int)n, (int)num_players, (const double *)b, (const int32_t *)(b + o_f),
+                     mean_reward, reward_refunded, (double *)(b + o_r));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(rewards_out_host, b + o_r, sb, hipMemcpyDeviceToHost));
+  return SKYJO_OK;
+}
+
 int skyjo_dev_copy(void *dst, const void *src, size_t bytes, int kind, void *stream) {
   hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
   HIPCHK(hipMemcpyAsync(dst, src, bytes, k, (hipStream_t)stream));

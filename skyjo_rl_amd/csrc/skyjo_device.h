@@ -65,6 +65,7 @@ struct SkParams {
   uint32_t *plan_ep;        // [tiles*64] episode index of that deal (pipelined dealing: see sk_plan_deals)
   uint32_t ov_flags;        // k_step, dealing beside it: 1 = publish finished deals on the way in, 2 = plan the next run on the way out
   uint32_t plan_new_tag;    // the id the planned run will have
+  uint32_t wg_local;        // 1 inside k_cycle: the dealing wavefront of a game and its step wavefront share a workgroup (SK_FENCE_*)
   uint32_t host_seq;        // != 0 (single-tile engines, host-style step): the wavefront's last store is this number into health_host[3]
   int32_t *deal_list;       // [2][tiles*64] games of the current / previous dealing launch (k_scan)
   uint32_t *deal_ep;        // [2][tiles*64] episode index of each listed deal
@@ -93,6 +94,27 @@ struct LaneCounters {
 // LDS addressing: lp = tile base + lane * 16 ; byte b of this lane's record lives at lp[LIDX(b)]
 // (chunk-major, skyjo_layout.h); LQ(c) is the lane's whole 16-byte chunk c (one ds_read_b128 / ds_write_b128).
 // ------------------------------------------------------------------------------------------
+// Hand-over of a dealt episode from the dealing wavefront (release) to the step wavefront (acquire).  Between two KERNELS
+// (the two-stream form) the two may sit on different XCDs, whose L2s are not coherent: agent scope, i.e. buffer_wbl2 /
+// buffer_inv sc1 - a write-back / an invalidation of a whole L2 per wavefront, which is what made that form a net loss on a full
+// chip (EXPERIMENTS.md round 4: 25.7 -> 34.0 x 10^9 steps/s without them).  Inside k_cycle both are wavefronts of ONE workgroup,
+// i.e. of one CU - they share its vector L1 (write-through) and its XCD's L2: workgroup scope is all the memory model asks for,
+// and on gfx950 that is a wait for the wavefront's own stores and nothing else (P.wg_local).
+#ifdef SK_EXP_NO_FENCE  // timing build: no cache maintenance around the hand-over at all (results may be stale)
+#define SK_FENCE_ACQUIRE(P) asm volatile("" ::: "memory")
+#define SK_FENCE_RELEASE(P) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define SK_FENCE_ACQUIRE(P)                                              \
+  do {                                                                   \
+    if ((P).wg_local) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
+    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");              \
+  } while (0)
+#define SK_FENCE_RELEASE(P)                                              \
+  do {                                                                   \
+    if ((P).wg_local) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");              \
+  } while (0)
+#endif
 #define SK_RARE(x) __builtin_expect(!!(x), 0)
 #define SK_OFTEN(x) __builtin_expect(!!(x), 1)
 #define LIDX(b) ((((b) >> 4) << 10) | ((b) & 15))
@@ -218,6 +240,26 @@ struct Stamps {
 #define STAMP_DECL Stamps st
 #define STAMP(i)
 #define STAMP_STORE
+#endif
+
+// Diagnostic builds (-DSK_TRACE): where and when every wavefront ran - {HW_ID, XCC_ID, start, end (100 MHz real-time clock),
+// tag} per wavefront in P.stamps, two launches deep (slot = tag & 1): k_step rows [slot][tile], k_deal rows [2 + slot][tile]
+// (tools/dev/placement.py reads them through skyjo_vec_debug_trace).  The shipped build has none of it.
+#ifdef SK_TRACE
+#define TRACE_DECL const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime(), trace_c0 = __builtin_amdgcn_s_memtime()
+#define TRACE_STORE(kind, tag, lane_, block_)                                                                    \
+  do {                                                                                                           \
+    if ((lane_) == 0) {                                                                                          \
+      unsigned long long *tr = P.stamps + (((size_t)(2 * (kind) + ((tag) & 1u)) * P.tiles + (block_)) * 8);     \
+      tr[0] = __builtin_amdgcn_s_getreg(63492); /* HW_REG_HW_ID, 32 bits */                                      \
+      tr[1] = __builtin_amdgcn_s_getreg(63508); /* HW_REG_XCC_ID */                                              \
+      tr[2] = trace_t0, tr[3] = __builtin_amdgcn_s_memrealtime(), tr[4] = (tag);                                 \
+      tr[5] = __builtin_amdgcn_s_memtime() - trace_c0; /* shader cycles: / (end - start) x 100 MHz = the clock */ \
+    }                                                                                                            \
+  } while (0)
+#else
+#define TRACE_DECL
+#define TRACE_STORE(kind, tag, lane_, block_)
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -490,7 +532,7 @@ __device__ __forceinline__ int wait_deal_done(const SkParams &P, int g) {
     atomicOr(P.dev_error, SK_ERR_DEAL_TIMEOUT);  // (the host-style kernels hand the word to the host: sk_error_to_host)
     return SK_WAIT_TIMEOUT;
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  SK_FENCE_ACQUIRE(P);
   return (f >> 31) != 0 ? SK_WAIT_GAVE_UP : SK_WAIT_OK;
 }
 
@@ -1115,13 +1157,13 @@ __device__ __forceinline__ void sk_publish_deals(const SkParams &P, int g) {
     const uint32_t tag = P.plan_tag[g];
     const uint32_t f = __hip_atomic_load(&P.done_flag[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((f & 0x7fffffffu) == tag) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the record the dealing lane released is what a later reset of this game reads
+      SK_FENCE_ACQUIRE(P);  // the record the dealing lane released is what a later reset of this game reads
       if (!P.cancel[g] && f == tag) P.spare_ready[(size_t)(b - 1) * G + g] = 1;  // (bit 31: the deal gave itself up)
       P.busy[g] = 0, P.cancel[g] = 0;
     }
   }
 }
-__device__ __forceinline__ void sk_plan_deals(const SkParams &P, int g) {
+__device__ __forceinline__ void sk_plan_deals(const SkParams &P, int g, int lane) {
   const size_t G = (size_t)P.tiles * SK_TILE;
   bool need = false, empty = false;
   if (g < P.B) {
@@ -1151,7 +1193,7 @@ __device__ __forceinline__ void sk_plan_deals(const SkParams &P, int g) {
     }
   }
   const unsigned long long be = __ballot(empty);
-  if (be && threadIdx.x == 0) atomicAdd(P.bank_empty + (P.plan_new_tag & 1u), (uint32_t)__popcll(be));  // (rare)
+  if (be && lane == 0) atomicAdd(P.bank_empty + (P.plan_new_tag & 1u), (uint32_t)__popcll(be));  // (rare)
 }
 
 // Small batches, host-style calls (single-game views): the lane hands its whole game to the host with the records - the
@@ -1164,8 +1206,8 @@ __device__ __forceinline__ void sk_plan_deals(const SkParams &P, int g) {
 // raised error on: the wavefront that raises one reaches its own end after the atomicOr, however long it spun - so the very
 // host call whose kernel timed out sees the error.  Kernels never clear the host's word (skyjo_vec_seed and
 // skyjo_vec_snapshot_restore do).
-__device__ __forceinline__ void sk_error_to_host(const SkParams &P) {
-  if (threadIdx.x == 0) {
+__device__ __forceinline__ void sk_error_to_host(const SkParams &P, int lane) {
+  if (lane == 0) {
     const uint32_t e = __hip_atomic_load(P.dev_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (e) P.health_host[2] = e;
   }
@@ -1179,14 +1221,16 @@ __device__ __forceinline__ void sk_export_raw(const SkParams &P, uint8_t *lp, in
   m[1] = P.done[g];
 }
 
+// The body of the step kernel for ONE wavefront: tile `tile`, its lanes 0..63, its own LDS region `lds_raw` (k_step: the
+// workgroup IS that wavefront; k_cycle: four such wavefronts share a workgroup with four dealing wavefronts).
 template <bool INDIRECT, bool POLICY, int NP>
-__global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *actions, uint8_t *rec_out,
-                                                  int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0,
-                                                  double *end_rew_out, uint8_t *end_out, uint8_t *raw_out, int raw_stride) {
+__device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, const int lane, uint32_t *lds_raw, const int32_t *actions,
+                                          uint8_t *rec_out, int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0,
+                                          double *end_rew_out, uint8_t *end_out, uint8_t *raw_out, int raw_stride) {
   SkParams P = Pin;
+  TRACE_DECL;
   if (NP > 0) P.L = sk_make_layout(NP, INDIRECT ? 1 : 0);  // same values as the host computed, now constants
-  extern __shared__ uint32_t lds_raw[];
-  const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
+  const int g = tile * SK_TILE + lane;
   const uint32_t lds_tile = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_raw;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 16;
   // LDS map: the tile | one iteration's records (4 KiB for the 64-byte records) | the wavefront's statistics.  The 16-word
@@ -1413,7 +1457,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   tile_store_nt(P, P.state, tile, lane, lp);
   if (!POLICY && raw_out && valid) sk_export_raw(P, lp, g, raw_out + (size_t)g * raw_stride);
   if (!POLICY) {
-    sk_error_to_host(P);
+    sk_error_to_host(P, lane);
     if (P.host_seq) {
       // ONE tile = this wavefront is the whole launch: everything the host reads back (records, exported games, error word)
       // has been stored by it - make that visible system-wide, then tell the host, which is spinning on the word instead of
@@ -1431,7 +1475,7 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
       if (P.busy[g]) (void)wait_deal_done(P, g);  // (after a timeout the deal stays busy: sk_publish_deals looks at its flag again)
       sk_publish_deals(P, g);
     }
-    sk_plan_deals(P, g);
+    sk_plan_deals(P, g, lane);
   }
   // per-wavefront event counts go to the tile's own slot: thousands of same-address atomics at the
   // end of a launch would serialise at ~12 ns each (MI355X_MICROARCH.md, "fanin")
@@ -1468,6 +1512,16 @@ __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *a
   }
   STAMP(7);
   STAMP_STORE;
+  TRACE_STORE(0, (uint32_t)(iter0 / (uint64_t)(iters > 0 ? iters : 1)), lane, tile);
+}
+
+template <bool INDIRECT, bool POLICY, int NP>
+__global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *actions, uint8_t *rec_out,
+                                                  int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0,
+                                                  double *end_rew_out, uint8_t *end_out, uint8_t *raw_out, int raw_stride) {
+  extern __shared__ uint32_t lds_raw[];
+  step_body<INDIRECT, POLICY, NP>(Pin, (int)blockIdx.x, (int)threadIdx.x, lds_raw, actions, rec_out, act_out, iters, policy_seed, iter0,
+                                  end_rew_out, end_out, raw_out, raw_stride);
 }
 
 // SimpleSkyjoEnv.observe(agent) (skyjo_env.py:199-214) for arbitrary players; state untouched.
@@ -1476,7 +1530,7 @@ __global__ __launch_bounds__(SK_TILE) void k_observe(SkParams P, const int32_t *
   extern __shared__ uint32_t lds_raw[];
   const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 16;
-  sk_error_to_host(P);
+  sk_error_to_host(P, lane);
   tile_load(P, P.state, tile, lane, lp);
   if (!(LB(H_FLAGS) & F_VALID)) return;
   HdrRegs h;
@@ -1515,7 +1569,7 @@ __global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *ma
   }
   if (want) tile_store(P, P.state, tile, lane, lp);
   if (raw_out && (LB(H_FLAGS) & F_VALID)) sk_export_raw(P, lp, g, raw_out + (size_t)g * raw_stride);
-  sk_error_to_host(P);
+  sk_error_to_host(P, lane);
   const unsigned long long wb = __ballot(want_counted);
   if (want_counted && lane == __ffsll((long long)wb) - 1) P.tile_counters[(size_t)tile * 8 + 3] += __popcll(wb);
 }
@@ -1668,6 +1722,14 @@ struct MtChunkStream {
   __device__ __forceinline__ int close() const { return wrap(base + pos) | (((16 - pos) & 31) << 16); }
   __device__ __forceinline__ void issue() {
     const int c = gen;
+#ifdef SK_EXP_DEAL_NO_LOADS  // timing build (results wrong on purpose): no generator-state loads at all
+#pragma unroll
+    for (int k = 0; k < 17; k++) o[k] = (my_off + (uint32_t)c + (uint32_t)k) * 2654435761u;
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = o[k] ^ (o[k + 1] >> 7);
+    xw = x[3];
+    return;
+#endif
     const uint4 *po = (const uint4 *)(mt + c);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1675,6 +1737,12 @@ struct MtChunkStream {
       o[4 * k] = q.x, o[4 * k + 1] = q.y, o[4 * k + 2] = q.z, o[4 * k + 3] = q.w;
     }
     o[16] = mt[c + 16 == 624 ? 0 : c + 16];
+#ifdef SK_EXP_DEAL_NO_PARTNERS  // timing build: the chunk itself is loaded, its partners are not
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = o[k] ^ (o[k + 1] >> 7);
+    xw = x[3];
+    return;
+#endif
     // The partners i + 397 (mod 624), without a branch (with the two cases in two exec-masked blocks the compiler merges their
     // registers behind each block and waits for the loads right there, a few instructions after they were issued).  Chunk 224 is the one whose partners wrap (621, 622, 623,
     // 0 .. 12): its pieces 1 .. 3 are words 1 .. 12 = (224 - 227) + 4 k like every chunk above it, piece 0 is read at 621
@@ -1715,7 +1783,15 @@ struct MtChunkStream {
     gen = live ? (c + 16 == 624 ? 0 : c + 16) : c;
     const uint32_t lm = live ? 0xffffffffu : 0u;  // (a select the compiler cannot turn into a branch around the tempering)
 #pragma unroll
+#ifdef SK_EXP_DEAL_NO_TEMPER  // timing build: six vector instructions fewer per output
+    for (int k = 0; k < 16; k++) R[k] = __builtin_amdgcn_bitop3_b32(R[k], v[k], lm, 0xd8);
+#else
     for (int k = 0; k < 16; k++) R[k] = __builtin_amdgcn_bitop3_b32(R[k], mt_temper3(v[k]), lm, 0xd8);
+#endif
+#ifdef SK_EXP_DEAL_NO_STORES  // timing build: the regenerated chunk is not written back
+    issue();
+    return;
+#endif
     uint8_t *row = stg + lane * SK_STG_STRIDE;
 #pragma unroll
     for (int k = 0; k < 4; k++) ((uint4 *)row)[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
@@ -1793,6 +1869,13 @@ __device__ __forceinline__ void deck_batch(Rng &r, const int s, uint32_t *lds_ra
   }
   w.nxt_n = w.pb == dk ? R : 0u;  // (a batch never holds two completions: the rest takes > 100 draws)
   uint32_t cI[BS], cJ[BS];
+#ifdef SK_EXP_DEAL_NO_DECK  // timing build: the walk's arithmetic without its LDS accesses
+#pragma unroll
+  for (int k = 0; k < BS; k++) cI[k] = pI[k] & 15u, cJ[k] = pJ[k] & 15u;
+  asm volatile("" : "+v"(cI[0]), "+v"(cJ[0]), "+v"(cI[BS - 1]), "+v"(cJ[BS - 1]));
+  w.nxt_n ^= (cI[0] ^ cJ[BS - 1]) >> 20;  // (keeps the values alive; always zero)
+  return;
+#endif
 #pragma unroll
   for (int k = 0; k < BS; k++) cI[k] = DK_AT(pI[k]), cJ[k] = DK_AT(pJ[k]);
   // What step k finds at its two positions is what the batch's earlier steps left there.  Only an earlier step's
@@ -2175,25 +2258,25 @@ __global__ __launch_bounds__(256) void k_publish_all(SkParams P) {
   if (g < P.tiles * SK_TILE) sk_publish_deals(P, g);
 }
 
+// One dealing wavefront: games block * 64 .. (lane = game in the forms without a work list), its own LDS region `lds_raw`.
 template <int NP>
-__global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int publish_inline) {
-  extern __shared__ uint32_t lds_raw[];
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void deal_body(const SkParams &P, int list_sel, int publish_inline, const int block, const int lane, uint32_t *lds_raw) {
+  TRACE_DECL;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 16;
   const size_t G = (size_t)P.tiles * SK_TILE;
   const int count = (int)P.deal_count[list_sel];
-  const int i = blockIdx.x * SK_TILE + lane;
+  const int i = block * SK_TILE + lane;
   // publish_inline == 2: in line AND its own scan - lane = game, every lane looks at its game's bank itself (what k_scan
   // does, minus the work list: no launch in front of this one; the lanes whose bank is full idle through the refill loops)
   // publish_inline == 3: beside the step kernel, lane = game as well - the step kernel planned this run on its way out
   // (sk_plan_deals) and publishes it on its way into a later launch; this kernel deals and signals, as with a work list
   const bool fused = publish_inline == 2, piped = publish_inline == 3;
-  if (piped && blockIdx.x == 0 && lane == 0) {
+  if (piped && block == 0 && lane == 0) {
     uint32_t *be = P.bank_empty + (P.deal_tag & 1u);  // the launch that planned this run has finished: its count is complete
     P.health_host[0] = *be, P.health_host[1] = P.deal_tag;
     *be = 0;
   }
-  if (!piped && publish_inline && blockIdx.x == 0 && lane == 0) {
+  if (!piped && publish_inline && block == 0 && lane == 0) {
     P.deal_count[list_sel ^ 1] = 0;  // for the next run's k_scan
     // (host-mapped memory: the host adapts the dealing interval.)  Fused, this run's count of empty banks is still being
     // added up by the other wavefronts: the previous run's goes out, each run counts into the word of its list_sel.
@@ -2201,9 +2284,9 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
     P.health_host[0] = *be, P.health_host[1] = P.deal_tag;
     *be = 0;
   }
-  if (!fused && !piped && blockIdx.x * SK_TILE >= count) return;
+  if (!fused && !piped && block * SK_TILE >= count) return;
   for (uint32_t k = 0; k < P.debug_deal_delay; k++) __builtin_amdgcn_s_sleep(127);  // (fault injection only: 0 in production)
-  const int tile = blockIdx.x;  // stamp slot
+  const int tile = block;  // stamp slot
   (void)tile;
   STAMP_DECL;
   STAMP(0);
@@ -2314,7 +2397,7 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
     }
   } else {
     // hand the finished deals over: every store above must be visible device-wide before the flag is
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    SK_FENCE_RELEASE(P);
     if (act)
       __hip_atomic_store(&P.done_flag[g], P.deal_tag | (mt_overrun ? 0x80000000u : 0u), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
@@ -2323,6 +2406,97 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
   if (lane == 0 && tile < P.tiles)
     for (int k = 0; k < 8; k++) P.stamps[(size_t)(P.tiles + tile) * 8 + k] += st.acc[k];
 #endif
+  TRACE_STORE(1, P.deal_tag, lane, block);
+}
+
+template <int NP>
+__global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int publish_inline) {
+  extern __shared__ uint32_t lds_raw[];
+  deal_body<NP>(P, list_sel, publish_inline, (int)blockIdx.x, (int)threadIdx.x, lds_raw);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_cycle: one kernel per dealing cycle - stepping and dealing side by side inside every workgroup (fused rollout, two to
+// four players, indirect observation).
+//
+// A workgroup is S step wavefronts + S dealing wavefronts on one CU (S = 4 on a full chip: eight wavefronts, two per SIMD;
+// S = 1 .. 3 for batches of up to 256 .. 768 tiles, every wavefront on a SIMD of its own).  The dealing wavefronts deal for the
+// games of THEIR OWN workgroup's tiles, the run that the previous launch planned on its way out (the pipelined protocol of
+// the two-stream form, unchanged: sk_plan_deals / sk_publish_deals / wait_deal_done; `deal_tag_run` is that run's id, 0 =
+// nothing to deal in this launch).  So the hand-over of a dealt episode never leaves the CU: the two wavefronts share its
+// vector L1 and its XCD's L2, and workgroup-scope release / acquire - a wait for the wavefront's own stores - is all it
+// takes (P.wg_local).  The two-stream form has to use agent scope (the kernels' wavefronts may sit on different XCDs), i.e. a
+// write-back / an invalidation of a whole L2 per wavefront: THAT, not the sharing of SIMDs, is what made dealing beside the
+// step kernel a net loss on a full chip for three rounds (EXPERIMENTS.md round 4: two-stream form 25.7, the same without its
+// cache maintenance 34.0, this kernel 36 - 37 x 10^9 env-steps/s against 30.5 in line).
+//
+// Roles on a full chip: the first wavefront to arrive on a SIMD steps, the second deals - one of each per SIMD, where they
+// hide each other's latencies (two dealing wavefronts on one SIMD saturate its vector ALU: 32.5 instead of 35.8 x 10^9).  Tiles
+// are claimed through LDS counters; nothing depends on how the hardware spreads the wavefronts.
+// ------------------------------------------------------------------------------------------
+#define SK_CYCLE_MAX_S 4
+template <bool INDIRECT, int NP>
+__global__ __launch_bounds__(2 * SK_CYCLE_MAX_S *SK_TILE) void k_cycle(SkParams Pin, uint8_t *rec_out, int32_t *act_out, int iters, uint64_t policy_seed,
+                                                                        uint64_t iter0, uint32_t deal_tag_run, uint32_t lds_step_bytes,
+                                                                        uint32_t lds_deal_bytes) {
+  extern __shared__ uint32_t lds_raw[];
+  const uint32_t S = blockDim.x >> 7;  // step (= dealing) wavefronts per workgroup
+  const uint32_t split = lds_deal_bytes >> 30;  // (diagnostic role splits, see below)
+  lds_deal_bytes &= 0x3fffffffu;
+  uint32_t *claim = lds_raw + (((size_t)S * (lds_step_bytes + lds_deal_bytes)) >> 2);  // six words behind the 2 S regions
+  const int lane = (int)(threadIdx.x & 63u);
+  if (threadIdx.x < 6) claim[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t simd = (__builtin_amdgcn_s_getreg(63492) >> 4) & 3u;  // HW_REG_HW_ID[5:4]
+  uint32_t role = 0, slot = 0;
+  if (split == 0) {
+    if (lane == 0) role = atomicAdd(&claim[2 + simd], 1u) & 1u;
+    role = (uint32_t)__builtin_amdgcn_readfirstlane((int)role);
+  } else {  // diagnostic: two of a kind per SIMD - by SIMD parity (1) or by SIMD pair (2)
+    role = split == 1 ? simd & 1u : (simd >> 1) & 1u;
+  }
+  if (lane == 0) slot = atomicAdd(&claim[role], 1u);
+  slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+  if (slot >= S) {  // the preferred role is taken S times over (always the case for S < 4, where every wavefront asks to step first)
+    role ^= 1u;
+    if (lane == 0) slot = atomicAdd(&claim[role], 1u);
+    slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+  }
+  const int unit = (int)(blockIdx.x * S + slot);
+  if (unit >= Pin.tiles) return;
+  Pin.wg_local = 1u;  // the games of tile `unit` are dealt by dealing slot `slot` of THIS workgroup: hand-overs stay inside the CU
+  if (role == 0) {
+    step_body<INDIRECT, true, NP>(Pin, unit, lane, lds_raw + (size_t)slot * (lds_step_bytes >> 2), nullptr, rec_out, act_out, iters, policy_seed, iter0,
+                                  nullptr, nullptr, nullptr, 0);
+#ifdef SK_EXP_CYCLE_SYNTH  // diagnostic: the second wavefront of every SIMD runs a synthetic stream of vector instructions instead
+  } else {
+    uint32_t x = (uint32_t)lane * 2654435761u + (uint32_t)unit, y = x ^ 0x9e3779b9u;
+#if SK_EXP_CYCLE_SYNTH == 1  // a loop of a few instructions (no instruction-fetch traffic to speak of)
+#pragma unroll 1
+    for (int k = 0; k < 12000; k++) {
+      x = (x ^ (y >> 3)) + 0x7f4a7c15u, y = (y ^ (x << 5)) + x;
+      x = (x ^ (y >> 7)) + 0x2545f491u, y = (y ^ (x << 9)) + x;
+      asm volatile("" : "+v"(x), "+v"(y));
+    }
+#else  // the same arithmetic as 30 000 instructions of straight-line code, run 4 times (every instruction fetched anew)
+#pragma unroll 1
+    for (int rep = 0; rep < 4; rep++) {
+#pragma unroll
+      for (int k = 0; k < 3000; k++) {
+        x = (x ^ (y >> 3)) + 0x7f4a7c15u + (uint32_t)k, y = (y ^ (x << 5)) + x;
+        x = (x ^ (y >> 7)) + 0x2545f491u, y = (y ^ (x << 9)) + x;
+        asm volatile("" : "+v"(x), "+v"(y));
+      }
+    }
+#endif
+    if (x == 0x12345678u && y == 1u) Pin.stamps[0] = x;  // (keeps the stream alive)
+#else
+  } else if (deal_tag_run) {
+    SkParams P = Pin;
+    P.deal_tag = deal_tag_run;
+    deal_body<NP>(P, 0, 3, unit, lane, lds_raw + (((size_t)S * lds_step_bytes + (size_t)slot * lds_deal_bytes) >> 2));
+#endif
+  }
 }
 
 // per-seat sums over all games for skyjo_vec_get_counters (the hot path keeps per-game sums, no atomics)
@@ -2456,5 +2630,51 @@ __global__ void k_unpack(SkLayout L, const uint8_t *rec, long long n, int8_t *ob
       if (done) done[r] = src[L.Dp + 28];
       if (status) status[r] = src[L.Dp + 29];
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The reference's two scoring helpers for CALLER-SUPPLIED hands (its notebook calls them directly), one lane per hand set:
+//   k_evaluate_game   SkyjoGame._evaluate_game(players_cards, player_won_id, score_penalty)   skyjo.py:477-498
+//   k_final_rewards   SimpleSkyjoEnv._calc_final_rewards(final_score, num_refunded)           skyjo_env.py:293-312
+// float64 with numpy's operation order (np.mean = pairwise sum: left to right below eight addends, eight partial sums
+// from eight on), no contraction (-ffp-contract=off) - the arithmetic of finish_game, outside a game.
+// ------------------------------------------------------------------------------------------
+__global__ void k_evaluate_game(int n, int N, const int8_t *cards, const int32_t *won, double penalty, double *scores) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int8_t *c = cards + (size_t)i * N * 12;
+  double sc[SKYJO_MAX_PLAYERS], mn = 0.0;
+  for (int p = 0; p < N; p++) {
+    int s = 0;
+    for (int k = 0; k < 4; k++) {
+      const int t0 = c[12 * p + 3 * k], t1 = c[12 * p + 3 * k + 1], t2 = c[12 * p + 3 * k + 2];
+      if (!(t0 == t1 && t1 == t2)) s += t0 + t1 + t2;  // skyjo.py:488-493: min != max of the stack of three
+    }
+    sc[p] = (double)s;
+    mn = (p == 0 || sc[p] < mn) ? sc[p] : mn;
+  }
+  const int w = won[i];
+  for (int p = 0; p < N; p++) scores[(size_t)i * N + p] = (p == w && mn != sc[p]) ? sc[p] * penalty : sc[p];  // skyjo.py:496-497
+}
+
+__global__ void k_final_rewards(int n, int N, const double *score, const int32_t *refunded, double mean_reward, double reward_refunded,
+                                double *rew) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double *a = score + (size_t)i * N;
+  double sum;
+  if (N < 8) {
+    sum = 0.0;
+    for (int p = 0; p < N; p++) sum += a[p];
+  } else {
+    sum = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    for (int p = 8; p < N; p++) sum += a[p];
+  }
+  const double mean = sum / (double)N;
+  for (int p = 0; p < N; p++) {
+    double r = (-a[p] + mean) + mean_reward;
+    if (reward_refunded != 0.0) r += (double)refunded[(size_t)i * N + p] * reward_refunded;  // skyjo_env.py:309-310
+    rew[(size_t)i * N + p] = r;
   }
 }

@@ -249,6 +249,24 @@ class SkyjoGame(object):
     def get_game_metrics(self):
         return self.game_metrics
 
+    @staticmethod
+    def _evaluate_game(players_cards, player_won_id, score_penalty: float = 2.0, device=0):
+        """``SkyjoGame._evaluate_game`` (skyjo.py:477-498) for caller-supplied hands - the reference's notebook calls it
+        directly (notebooks/trainpettingzoo.ipynb:52745-52758).  ``players_cards`` int8 [num_players, 12]; returns the list of
+        scores.  Computed by the engine's own scoring arithmetic on the device (``skyjo_vec_evaluate_game``): there is no host
+        implementation behind this."""
+        import ctypes as C
+
+        from . import _lib
+
+        cards = np.ascontiguousarray(players_cards, dtype=np.int8)
+        assert cards.ndim == 2 and cards.shape[1] == 12, "players_cards must be [num_players, 12]"
+        won = np.asarray([player_won_id], dtype=np.int32)
+        out = np.zeros(cards.shape[0], dtype=np.float64)
+        _lib.check(_lib.load().skyjo_vec_evaluate_game(int(device), 1, int(cards.shape[0]), cards.ctypes.data_as(C.c_void_p),
+                                                   won.ctypes.data_as(C.c_void_p), float(score_penalty), out.ctypes.data_as(C.c_void_p)))
+        return [float(x) for x in out]
+
     # ---- render utils: same text as skyjo.py:508-602 ------------------------------------------------
     def render_table(self):
         bar = "=" * 7

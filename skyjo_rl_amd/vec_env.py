@@ -323,8 +323,16 @@ class SkyjoVecEnv:
         return bool(v.value)
 
     def set_overlap(self, on):
-        """Run the dealing kernel on its own stream beside the step kernels (results do not depend on it)."""
-        _lib.check(self._L.skyjo_vec_set_option(self._h, 2, int(bool(on))))
+        """Dealing beside the step kernel (results do not depend on it).  False / 0: in line; True / 1: beside, in the form the
+        engine prefers; 2: the two-stream form (k_deal on a stream of its own); 3: the one-kernel form (k_cycle: step and dealing
+        wavefronts share every CU; two or three players, indirect observation)."""
+        _lib.check(self._L.skyjo_vec_set_option(self._h, 2, int(on)))
+
+    def dealing_form(self):
+        """'in line', 'two streams' or 'one kernel' (include/skyjo_vec.h: SKYJO_OPT_OVERLAP)."""
+        v = C.c_int64()
+        _lib.check(self._L.skyjo_vec_get_option(self._h, 2, C.byref(v)))
+        return {0: "in line", 2: "two streams", 3: "one kernel"}[int(v.value)]
 
 
     def set_debug_option(self, option, value):

@@ -5,6 +5,7 @@ rlskyjo/models/random_admissible_policy.py:26-28: choice(arange(26), p=mask/sum(
 oracle/gen_golden.py.  The on-device policy and the oracle's restatement of it draw from another
 random stream by construction, so they are held to the reference's DISTRIBUTIONS:
 
+  * variance of the episode length: the ratio to the fixture's sample variance within 4.5 standard errors of a sample variance,
   * mean episode length, mean num_refunded and mean final score per seat: within 4 standard errors
     (the fixture's sample variance / its 6 000 games + the candidate's own, which is far smaller),
   * the histogram of episode lengths and the histogram of "how many legal actions did the turn have":
@@ -89,8 +90,11 @@ def check_against_reference(c: Candidate):
     var_len = float((c.len_hist * lens.astype(np.float64) ** 2).sum() / n_c - (c.sum_len / n_c) ** 2)
     mean_check("episode length", c.sum_len / n_c, ep_len, var_len)
     # (the variance of the lengths themselves, as a ratio: chi-square interval of the fixture's sample variance)
+    # Var(s^2) = sigma^4 (2 / (n - 1) + excess kurtosis / n): the lengths are skewed, so the kurtosis term counts
     ratio = float(np.var(ep_len, ddof=1)) / var_len
-    lo, hi = stats.chi2.ppf([1e-5, 1 - 1e-5], n_ref - 1) / (n_ref - 1)
+    kurt = float(stats.kurtosis(ep_len, fisher=True, bias=False))
+    se_ratio = np.sqrt(2.0 / (n_ref - 1) + max(kurt, 0.0) / n_ref)
+    lo, hi = 1.0 - (SIGMAS + 0.5) * se_ratio, 1.0 + (SIGMAS + 0.5) * se_ratio
     assert lo < ratio < hi, f"variance of the episode length: reference / candidate = {ratio:.3f} outside [{lo:.3f}, {hi:.3f}]"
     report["episode length variance ratio"] = ratio
     mean_check("refunds per episode", float(c.sum_refunded.sum()) / n_c, refunded.sum(axis=1))

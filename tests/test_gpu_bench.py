@@ -30,7 +30,11 @@ def test_bench_line_carries_every_baseline_config():
     assert d["blocks"]["n"] == 3 and d["blocks"]["min"] <= d["value"] <= d["blocks"]["max"]
     assert abs(d["value"] - d["blocks"]["median"]) < 1e-6 * d["value"]
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["waits"] == 0
-    assert (d["roofline"]["traffic"] is None) == (d["roofline"]["traffic_source"] is None)
+    # the PMC traffic is reported only for the kernel sources it was measured on (sha256 stored with the digest): a figure, or
+    # null with the reason
+    assert d["roofline"]["traffic_source"]
+    assert (d["roofline"]["traffic"] is None) == (d["roofline_path"]["traffic"] is None)
+    assert d["scaling"] == "weak" and d["config"]["collective"]["ranks_gathered"] == 1 and d["config"]["collective"]["world_size"] == 1
     oc = d["other_configs"]
     for k in ("cfg2_4096x2", "cfg4_shard_32768x3", "cfg5_65536x4_model_fp32", "cfg5_65536x4_model_bf16", "philox_65536x3",
               "direct_obs_65536x3"):
@@ -51,6 +55,7 @@ def test_bench_two_ranks_on_one_card_rehearsal_and_refusal():
     assert out.returncode != 0 and "refusing to let ranks share a card" in out.stderr
     d = _line(_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--blocks", "2", "--no-cpu-baseline", env={"SKYJO_BENCH_SHARED_GPU": "1"}))
     assert d["n_gpus"] == 2 and d["config"]["shared_gpu_rehearsal"] is True and d["episode_stats"]["ranks"] == 2
+    assert d["config"]["collective"] == dict(d["config"]["collective"], backend="gloo", ranks_gathered=2, world_size=2) and d["scaling"] == "weak"
     assert d["config"]["games_per_gpu"] == 65536 and d["value"] > 1e9 and "other_configs" not in d
     # the two shards together applied steps for 2 x 65 536 games: more than one shard could in the same iterations
     assert d["episodes"] > 2 * 65536
@@ -58,3 +63,8 @@ def test_bench_two_ranks_on_one_card_rehearsal_and_refusal():
     d4 = _line(_bench("--gpus", "2", "--config", "4", "--steps", "3", "--warmup", "1", "--blocks", "1", "--no-cpu-baseline",
                       env={"SKYJO_BENCH_SHARED_GPU": "1"}))
     assert d4["config"]["games_per_gpu"] == 32768 and d4["config"]["baseline_config"] == 4 and "262 144" in d4["config"]["parallelism"]
+    # strong scaling, stated as such: 65 536 games in total, half of them on each rank
+    ds = _line(_bench("--gpus", "2", "--total-games", "65536", "--steps", "3", "--warmup", "1", "--blocks", "1", "--no-cpu-baseline",
+                      env={"SKYJO_BENCH_SHARED_GPU": "1"}))
+    assert ds["scaling"] == "strong" and ds["config"]["games_per_gpu"] == 32768 and ds["config"]["games_total"] == 65536
+    assert ds["config"]["scaling_mode"].startswith("strong")

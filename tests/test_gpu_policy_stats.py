@@ -2,7 +2,7 @@
 REFERENCE's policy_ra loop (tests/golden/policy_stats.npz - written by oracle/gen_golden.py from the imported reference;
 rlskyjo/models/random_admissible_policy.py:26-28).  VERDICT r3 "weak" #2: the bit-exact tests compare the device's pick with the
 oracle's restatement of the same formula; this one pins the formula's DISTRIBUTION to the reference's.  What is compared and
-with which bounds: tests/policy_stats_checks.py.  65 536 games, every record of the rollout is read back on the device."""
+with which bounds: tests/policy_stats_checks.py.  16 384 games x 8 192 iterations (~ 1.3 million episodes per case), every record of the rollout is digested on the device."""
 import numpy as np
 import pytest
 
@@ -16,8 +16,11 @@ def test_on_device_policy_matches_the_reference_statistics(N, rng_mode):
     import torch
     from skyjo_rl_amd import SkyjoVecEnv
 
-    B, K = 65536, 64
-    launches = {2: 8, 3: 10, 4: 12}[N]   # ~ 6 episodes per game: ~ 400 000 episodes
+    # A run of T iterations only counts the episodes that END inside it, which favours short ones (the episode in progress
+    # at the end is the censored one): the mean is low by about var / T.  T = 8 192 makes that 0.02 .. 0.04 steps, a fraction of
+    # the fixture's standard error (0.16 .. 0.25), and ~ 100 episodes per game leave no trace of the common start either.
+    B, K = 16384, 64
+    launches = 128
     eng = SkyjoVecEnv(B, num_players=N, score_penalty=2.0, observe_other_player_indirect=True, mean_reward=1.0, reward_refunded=0.001,
                       rng_mode=rng_mode, auto_reset=True)
     eng.seed(None, 17)
@@ -46,7 +49,7 @@ def test_on_device_policy_matches_the_reference_statistics(N, rng_mode):
     c.len_hist = len_hist.cpu().numpy()
     c.episodes, c.sum_len = int(cnt["episodes"]), int(cnt["sum_len"])
     c.sum_score, c.sum_refunded = np.asarray(cnt["sum_score"], dtype=np.float64), np.asarray(cnt["sum_refunded"], dtype=np.float64)
-    assert cnt["illegal"] == 0 and c.episodes > 5 * B
+    assert cnt["illegal"] == 0 and c.episodes > 50 * B
     assert int(c.rank_counts.sum()) == int(cnt["steps"])
     report = psc.check_against_reference(c)
     print(N, rng_mode, {k: (tuple(round(x, 4) for x in v) if isinstance(v, tuple) else round(v, 4)) for k, v in report.items()})

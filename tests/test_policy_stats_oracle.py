@@ -38,7 +38,7 @@ def collect_from_oracle(N, B, chunks, K, threads):
 def test_oracle_policy_matches_the_reference_statistics(N):
     threads = min(8, os.cpu_count() or 1)
     B, K = 2048, 128
-    chunks = {2: 40, 3: 56, 4: 72}[N]   # ~ 65 episodes per game: > 130 000 episodes
+    chunks = {2: 40, 3: 56, 4: 72}[N]   # ~ 65 episodes per game: > 130 000 episodes (T ~ 5 000 .. 9 000: censoring bias var / T ~ 0.03)
     c = collect_from_oracle(N, B, chunks, K, threads)
     report = psc.check_against_reference(c)
     assert abs(report["episode length"][2]) < psc.SIGMAS

@@ -1,16 +1,19 @@
-"""Digest gpurun_out/final/ (written by tools/refresh_profiles.sh on the GPU box) into profiles/r3_*.  Run from the repo root."""
+"""Digest gpurun_out/final/ (written by tools/refresh_profiles.sh on the GPU box) into profiles/<round>_*.  Run from the repo root:
+    python tools/collect_profiles.py [r4]"""
 import collections, csv, glob, json, os, shutil, sys
+sys.path.insert(0, os.getcwd())
 src, dst = "gpurun_out/final", "profiles"
+R = sys.argv[1] if len(sys.argv) > 1 else "r4"
 def find(pat):  # newest match: gpurun merges every refresh into the same local directory
     r = sorted(glob.glob(os.path.join(src, pat), recursive=True), key=os.path.getmtime)
     return r[-1] if r else None
 def short(name):
     return name.split("(")[0].replace("void ", "").strip()
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-json.dump(bench, open(os.path.join(dst, "r3_bench.json"), "w"), indent=1)
-shutil.copy(find("trace/**/*kernel_stats.csv"), os.path.join(dst, "r3_kernel_stats.csv"))
+json.dump(bench, open(os.path.join(dst, R + "_bench.json"), "w"), indent=1)
+shutil.copy(find("trace/**/*kernel_stats.csv"), os.path.join(dst, R + "_kernel_stats.csv"))
 tb = json.loads(open(os.path.join(src, "trace_bench.json")).read().strip().splitlines()[-1])
-json.dump(tb, open(os.path.join(dst, "r3_bench_under_rocprof.json"), "w"), indent=1)
+json.dump(tb, open(os.path.join(dst, R + "_bench_under_rocprof.json"), "w"), indent=1)
 # kernel trace digest: every dispatch's duration; the last 32 full k_step launches are bench.py's roofline leg
 rows = list(csv.DictReader(open(find("trace/**/*kernel_trace.csv"))))
 per = collections.defaultdict(list)
@@ -26,7 +29,7 @@ for k, v in per.items():
                    "min_us": min(d), "max_us": max(d)})
 digest.append({"note": "same run, bench.py's own HIP-event figure for the last 32 k_step launches",
                "avg_launch_ms": tb["roofline"]["avg_launch_ms"], "deal_kernel_avg_ms": tb["roofline"]["deal_kernel_avg_ms"]})
-json.dump(digest, open(os.path.join(dst, "r3_kernel_trace_digest.json"), "w"), indent=1)
+json.dump(digest, open(os.path.join(dst, R + "_kernel_trace_digest.json"), "w"), indent=1)
 # PMC passes
 pmc = {}
 for tag in ("fetch", "write", "sq", "sq2", "ea", "l2"):
@@ -38,11 +41,14 @@ for tag in ("fetch", "write", "sq", "sq2", "ea", "l2"):
         k = short(r["Kernel_Name"])
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
     pmc[tag] = {k: dict({"dispatches": len(n[k])}, **{c: v / len(n[k]) for c, v in agg[k].items()}) for k in agg}
-json.dump(pmc, open(os.path.join(dst, "r3_pmc_per_dispatch.json"), "w"), indent=1)
+json.dump(pmc, open(os.path.join(dst, R + "_pmc_per_dispatch.json"), "w"), indent=1)
 ks = [k for k in pmc["fetch"] if k.startswith("k_step")][0]
 fk, wk = pmc["fetch"][ks]["FETCH_SIZE"], pmc["write"][ks]["WRITE_SIZE"]
 kd = [k for k in pmc["fetch"] if k.startswith("k_deal")][0]
+import bench as bench_py  # (module level only defines functions and constants)
 traffic = {
+    "kernel_source_sha256": bench_py.kernel_source_sha256(),  # bench.py reports this traffic only for these very sources
+    "kernel_sources": list(bench_py.KERNEL_SOURCES),
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/refresh_profiles.sh), bench.py --steps 30 "
               "--warmup 10, 65536 x 3-player games, per k_step dispatch (88 lockstep iterations)",
     "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
@@ -60,13 +66,13 @@ if "ea" in pmc:  # the dealing kernel at the fabric: read requests by size (near
         "read_bytes": int(rd128 * 128 + (rd - rd128) * 64), "write_bytes": int(wr64 * 64 + (wr - wr64) * 32),
         "note": "per dealing run (k_deal dispatch): TCC_EA0_RDREQ[_128B] / TCC_EA0_WRREQ[_64B]; reads that are not 128-byte "
                 "requests counted as 64 bytes, writes that are not 64-byte requests as 32 bytes"}
-json.dump(traffic, open(os.path.join(dst, "r3_hbm_traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(dst, R + "_hbm_traffic.json"), "w"), indent=1)
 # config 5
 c5 = os.path.join(src, "cfg5.json")
 if os.path.exists(c5):
-    shutil.copy(c5, os.path.join(dst, "r3_cfg5_bench.json"))
+    shutil.copy(c5, os.path.join(dst, R + "_cfg5_bench.json"))
     f = find("trace_cfg5/**/*kernel_stats.csv")
     if f:
-        shutil.copy(f, os.path.join(dst, "r3_cfg5_kernel_stats.csv"))
+        shutil.copy(f, os.path.join(dst, R + "_cfg5_kernel_stats.csv"))
 print(json.dumps({"bench_value": bench["value"], "roofline": bench["roofline"], "traffic": traffic["k_step_bytes_per_launch"],
                   "digest": digest}, indent=1))
