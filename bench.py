@@ -75,15 +75,16 @@ def kernel_source_sha256():
     return h.hexdigest()
 
 
-def committed_traffic(shape_ok):
-    """(k_step bytes per launch, k_deal fabric bytes per run, source note) from the committed PMC digest - or (None, None,
-    reason) when the digest is missing, was taken for another launch shape, or for other kernel sources than the ones built."""
+def committed_traffic(shape):
+    """(dominant kernel's bytes per launch, dealing kernel's fabric bytes per run or None, source note) from the committed PMC digest
+    - or (None, None, reason) when the digest is missing, was taken for another launch shape (`shape`: games, players, iterations per
+    launch, rng, dealing form, records), or for other kernel sources than the ones built."""
     tpath = os.path.join(ROOT, TRAFFIC_PROFILE)
-    if not shape_ok:
-        return None, None, "no PMC digest for this launch shape (the committed one: 65 536 x 3, MT19937, 64-byte records, 88 iterations)"
     if not os.path.exists(tpath):
         return None, None, f"{TRAFFIC_PROFILE} not found"
     t = json.load(open(tpath))
+    if t.get("shape") != shape:
+        return None, None, f"no PMC digest for this launch shape (the committed one: {t.get('shape')})"
     if t.get("kernel_source_sha256") != kernel_source_sha256():
         return None, None, (f"{TRAFFIC_PROFILE} was measured on other kernel sources (sha256 {str(t.get('kernel_source_sha256'))[:16]} != "
                             f"{kernel_source_sha256()[:16]}): re-run tools/refresh_profiles.sh + tools/collect_profiles.py")
@@ -91,6 +92,10 @@ def committed_traffic(shape_ok):
     deal = fab.get("read_bytes", 0) + fab.get("write_bytes", 0) if fab else None
     return t.get("k_step_bytes_per_launch"), deal, (f"{TRAFFIC_PROFILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_* passes of this launch shape on these "
                                                      f"kernel sources, tools/refresh_profiles.sh; not measured in this run)")
+
+
+def launch_shape(B, N, chunk, rng, form, records, direct):
+    return {"games": int(B), "players": int(N), "iterations_per_launch": int(chunk), "rng": rng, "dealing": form, "records": bool(records), "direct_obs": bool(direct)}
 
 
 def algorithmic_bytes_per_launch(B, N, D, iters, records=True):
@@ -408,8 +413,10 @@ def main():
     achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # NOT measured in this run: PMC counters need rocprofv3 around the process.  The figure is the committed digest of this very
     # launch shape, and only if it was taken on the kernel sources that are built here (sha256 stored with it).
-    traffic, deal_traffic, traffic_source = committed_traffic(
-        B == 65536 and N == 3 and record and act is None and CHUNK == 88 and not args.direct_obs and args.rng == "mt19937")
+    shape = launch_shape(B, N, CHUNK, args.rng, eng.dealing_form(), record and act is None, args.direct_obs)
+    traffic, deal_traffic, traffic_source = committed_traffic(shape)
+    path_traffic = traffic if (traffic is not None and eng.dealing_form() == "one kernel") else (
+        traffic + deal_traffic if traffic is not None and deal_traffic is not None else None)  # (k_cycle's counters already hold both roles)
     kernel_ms = {k: prof[k + "_ms"] / 32.0 for k in ("k_step", "k_scan", "k_deal", "k_publish")}  # per bench step (= per dealing cycle)
     path_ms = sum(kernel_ms.values())
     wall_ms = 1e3 * t_max / args.steps
@@ -476,16 +483,15 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": (f"k_cycle<indirect,{N}> (step + dealing wavefronts of one dealing cycle)" if eng.dealing_form() == "one kernel" else
                                     f"k_step<{'indirect' if not args.direct_obs else 'direct'},policy,{N if N in (2, 3, 4) else 0}>"), "avg_launch_ms": avg_ms,
-                         "launches_timed": full, "algorithmic_bytes_per_launch": alg,
+                         "launches_timed": full, "algorithmic_bytes_per_launch": alg, "launch_shape": shape,
                          "deal_kernel_avg_ms": prof["deal_ms"] / max(prof["deal_launches"], 1)},
             "roofline_path": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                               "kernel_ms_per_step": kernel_ms, "kernel_ms_sum": path_ms,
                               "achieved_kernel_time": alg / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0,
                               "frac_kernel_time": alg / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if path_ms > 0 else 0.0,
                               "wall_ms_per_step": wall_ms,
-                              "traffic": (traffic + deal_traffic) if traffic is not None and deal_traffic is not None else None,
-                              "traffic_k_deal_fabric": deal_traffic, "traffic_source": traffic_source,
-                              "traffic_over_algorithmic": (traffic + deal_traffic) / alg if traffic is not None and deal_traffic is not None else None,
+                              "traffic": path_traffic, "traffic_k_deal_fabric": deal_traffic, "traffic_source": traffic_source,
+                              "traffic_over_algorithmic": path_traffic / alg if path_traffic is not None else None,
                               "achieved_wall": alg / (wall_ms * 1e-3) / 1e9,
                               "frac_wall": alg / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "k_deal": {"deals_per_step": deals_per_step, "rng_outputs_per_deal": rng_outputs_per_deal(N) if args.rng == "mt19937" else None,

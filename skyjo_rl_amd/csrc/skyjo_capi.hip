@@ -58,7 +58,14 @@ constexpr int kMaxRolloutChunk = 128;  // lockstep iterations per k_step launch 
 // caller's stream waits for every run; 80 / 56 in the pipelined form (the default), where a step launch should outlast
 // the dealing kernel beside it (32 768 x 3 players: 64 -> 17.5, 72 -> 19.0, 80 -> 19.4, 88 -> 19.9 x 10^9 steps/s with one
 // bank run dry; 4 096 x 2 players: 48 -> 2.3, 56 -> 2.7, 64 -> 2.9 x 10^9 with twelve).
-constexpr int deal_interval_default(int num_players, bool overlap, bool piped) {
+// The one-kernel form (k_cycle, merged_s = its S): on a full chip (S = 4, a step and a dealing wavefront on every SIMD) a launch
+// should last about as long as its dealing wavefronts - 65 536 x 3 players: 48 -> 32.7, 56 -> 36.0, 60 -> 37.1, 64 -> 37.3, 68 ->
+// 36.8, 72 -> 36.5, 80 -> 35.7 x 10^9 steps/s; two players: 40 -> 28.3, 48 -> 30.3, 56 -> 31.3 (64 empties banks).  With S < 4 every
+// wavefront has a SIMD to itself, the dealing is hidden anyway and longer launches win (32 768 x 3: 56 -> 22.4, 72 -> 23.2, 80 -> 23.4;
+// 32 768 x 4: 64 -> 22.6, 80 -> 23.1, 96 -> 23.7, 112 -> 24.0; 4 096 x 2: 40 -> 2.44, 48 -> 2.88, 56 -> 2.98).
+constexpr int deal_interval_default(int num_players, bool overlap, bool piped, int merged_s = 0) {
+  if (merged_s >= 4) return num_players >= 3 ? 64 : 56;
+  if (merged_s > 0) return num_players >= 4 ? 104 : (num_players == 3 ? 80 : 56);
   return overlap ? (piped ? (num_players >= 3 ? 80 : 56) : (num_players >= 3 ? 64 : 48)) : (num_players >= 3 ? 88 : 64);
 }
 
@@ -602,14 +609,16 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     }
     // Default: the one-kernel form wherever it fits (measured at 4 096 .. 65 536 games and two to four players: + 9 .. 32 % over the
     // two-stream form, + 18 .. 57 % over dealing in line, EXPERIMENTS.md round 4); SKYJO_MERGED=0 falls back to the older forms.
-    h->prefer_merged = true;
+    // (Batches beyond four tiles per CU would need a second round of workgroups - a workgroup's LDS fills its CU - where the in-line
+    // form simply runs six step wavefronts per CU: 98 304 x 3, counter-based deals: 34.5 against 39.8.)
+    h->prefer_merged = P.tiles <= SK_CYCLE_MAX_S * ncu;
     if (const char *e = getenv("SKYJO_MERGED")) h->prefer_merged = atoi(e) != 0;
     h->merged = h->merged_capable && h->prefer_merged && !getenv("SKYJO_OVERLAP");
     if (h->merged) h->overlap = false;  // (no second stream in this form)
   }
   if (const char *e = getenv("SKYJO_FUSED_SCAN")) h->fused_scan = atoi(e) != 0;
   if (const char *e = getenv("SKYJO_PIPELINED")) h->piped = atoi(e) != 0;
-  h->deal_every_iters = h->interval_default = deal_interval_default(cfg->num_players, h->overlap || h->merged, h->piped || h->merged);
+  h->deal_every_iters = h->interval_default = deal_interval_default(cfg->num_players, h->overlap, h->piped, h->merged ? h->cycle_s : 0);
   if (const char *e = getenv("SKYJO_DEAL_INTERVAL")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 1024) h->deal_every_iters = v, h->auto_interval = false;
@@ -1387,7 +1396,7 @@ int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
         return fail(SKYJO_E_INVALID, "the one-kernel form needs two to four players, the indirect observation and its workgroup's LDS regions within 160 KB");
       h->merged = value == 3 || (value == 1 && h->merged_capable && h->prefer_merged);
       h->overlap = value != 0 && !h->merged;
-      h->interval_default = deal_interval_default(h->P.L.N, h->overlap || h->merged, h->piped || h->merged);
+      h->interval_default = deal_interval_default(h->P.L.N, h->overlap, h->piped, h->merged ? h->cycle_s : 0);
       if (h->auto_interval) h->deal_every_iters = h->interval_default;
       return SKYJO_OK;
     }

@@ -46,12 +46,14 @@ def test_traffic_is_tied_to_the_kernel_sources_it_was_measured_on(tmp_path, monk
 
     sha = bench.kernel_source_sha256()
     assert len(sha) == 64 and sha == bench.kernel_source_sha256()
-    assert bench.committed_traffic(False)[0] is None and "launch shape" in bench.committed_traffic(False)[2]
+    shape = bench.launch_shape(65536, 3, 64, "mt19937", "one kernel", True, False)
     prof = tmp_path / "t.json"
     monkeypatch.setattr(bench, "TRAFFIC_PROFILE", str(prof))
-    assert bench.committed_traffic(True)[0] is None and "not found" in bench.committed_traffic(True)[2]
-    prof.write_text(json.dumps({"kernel_source_sha256": "0" * 64, "k_step_bytes_per_launch": 5}))
-    t = bench.committed_traffic(True)
+    assert bench.committed_traffic(shape)[0] is None and "not found" in bench.committed_traffic(shape)[2]
+    prof.write_text(json.dumps({"kernel_source_sha256": sha, "shape": dict(shape, games=4096), "k_step_bytes_per_launch": 5}))
+    assert bench.committed_traffic(shape)[0] is None and "launch shape" in bench.committed_traffic(shape)[2]
+    prof.write_text(json.dumps({"kernel_source_sha256": "0" * 64, "shape": shape, "k_step_bytes_per_launch": 5}))
+    t = bench.committed_traffic(shape)
     assert t[0] is None and t[1] is None and "other kernel sources" in t[2]
-    prof.write_text(json.dumps({"kernel_source_sha256": sha, "k_step_bytes_per_launch": 5, "k_deal_fabric": {"read_bytes": 3, "write_bytes": 4}}))
-    assert bench.committed_traffic(True)[:2] == (5, 7)
+    prof.write_text(json.dumps({"kernel_source_sha256": sha, "shape": shape, "k_step_bytes_per_launch": 5, "k_deal_fabric": {"read_bytes": 3, "write_bytes": 4}}))
+    assert bench.committed_traffic(shape)[:2] == (5, 7)

@@ -188,7 +188,8 @@ def test_handle_runs_on_its_device_from_any_thread():
     eng.close()
 
 
-def test_step_kernel_gives_up_loudly_when_the_dealing_kernel_never_arrives():
+@pytest.mark.parametrize("players,form", [(1, 2), (2, 3)], ids=["two_streams", "one_kernel"])
+def test_step_kernel_gives_up_loudly_when_the_dealing_kernel_never_arrives(players, form):
     """with the dealing kernel on its own stream a step kernel may have to wait for the one deal in flight for a
     game (bank empty, slot busy).  If that dealing launch does not make progress the wait is bounded and must NOT fall through
     silently: the kernel raises a sticky device error and skyjo_vec_get_counters fails until the engine is re-seeded.  Forced
@@ -197,15 +198,17 @@ def test_step_kernel_gives_up_loudly_when_the_dealing_kernel_never_arrives():
     import torch
     from skyjo_rl_amd import SkyjoNativeError
 
-    cfg = dict(CFG, num_players=1)
+    cfg = dict(CFG, num_players=players)
     eng = _engine(128, **cfg)
-    eng.set_overlap(True)
-    eng.set_deal_interval(120)
+    eng.set_overlap(form)   # 2: the two-stream form (one-player games use the generic kernels); 3: k_cycle - there the step wavefronts
+    #                         wait for the dealing wavefronts of their own workgroup on their way out of every launch
+    assert eng.dealing_form() == {2: "two streams", 3: "one kernel"}[form]
+    eng.set_deal_interval(120 if players == 1 else 30)
     eng.seed(None, 2)
     assert eng.counters()["steps"] == 0          # healthy so far
     eng.set_debug_option(3, 6)                   # give up after 64 polls
     eng.set_debug_option(4, 60000)               # each dealing wavefront sleeps 60000 x 8128 cycles ~ 0.2 s
-    eng.rollout(360, policy_seed=1)              # three dealing cycles: the banks run dry while the deals sleep
+    eng.rollout(360, policy_seed=1)              # dealing cycles whose wavefronts sleep: banks run dry / the step wavefronts' wait runs out
     with pytest.raises(SkyjoNativeError, match="gave up waiting for the dealing kernel"):
         eng.counters()
     # not only the counters - every synchronising call reports the voided run, and a snapshot of it is refused
@@ -219,6 +222,40 @@ def test_step_kernel_gives_up_loudly_when_the_dealing_kernel_never_arrives():
     eng.rollout(100, policy_seed=1)
     c = eng.counters()
     assert c["steps"] > 0 and c["episodes"] > 0
+    eng.check_error()
+    eng.close()
+
+
+def test_the_very_host_call_whose_kernel_timed_out_fails():
+    """the sticky device error reaches the host from EVERY wavefront of the host-style kernels, not only from tile 0
+    (which ends long before a tile that spins through its timeout): a `step_host` that returns normally must leave nothing for
+    `check_error` to find.  Two tiles of one-player games, the two-stream form, dealing wavefronts that sleep, a short spin
+    limit: some `step_host` call has to fail - and none may succeed while the device word is already raised."""
+    from skyjo_rl_amd import SkyjoNativeError
+
+    cfg = dict(CFG, num_players=1)
+    eng = _engine(128, **cfg)
+    eng.set_overlap(2)
+    eng.set_deal_interval(40)
+    eng.seed(None, 4)
+    eng.set_debug_option(3, 6)
+    eng.set_debug_option(4, 60000)
+    failed_at = None
+    for t in range(400):
+        try:
+            o = eng.observe_host()
+            acts = np.argmax(o.action_mask, axis=1).astype(np.int32)
+            eng.step_host(acts)
+        except SkyjoNativeError as e:
+            assert "gave up waiting for the dealing kernel" in str(e)
+            failed_at = t
+            break
+        eng.check_error()  # a host call that came back clean leaves no raised error behind
+    assert failed_at is not None and failed_at > 10, failed_at
+    eng.set_debug_option(4, 0)
+    eng.set_debug_option(3, 22)
+    eng.seed(None, 4)
+    eng.step_host(np.full(128, 24, dtype=np.int32))
     eng.check_error()
     eng.close()
 

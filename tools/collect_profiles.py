@@ -21,7 +21,7 @@ for r in rows:
     per[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
 digest = []
 for k, v in per.items():
-    if not (k.startswith("k_step") or k.startswith("k_deal") or k in ("k_scan", "k_publish")):
+    if not (k.startswith("k_step") or k.startswith("k_deal") or k.startswith("k_cycle") or k in ("k_scan", "k_publish")):
         continue
     v.sort()
     d = [x[1] for x in v]
@@ -32,7 +32,7 @@ digest.append({"note": "same run, bench.py's own HIP-event figure for the last 3
 json.dump(digest, open(os.path.join(dst, R + "_kernel_trace_digest.json"), "w"), indent=1)
 # PMC passes
 pmc = {}
-for tag in ("fetch", "write", "sq", "sq2", "ea", "l2"):
+for tag in ("fetch", "write", "sq", "sq2", "ea", "l2", "issue"):
     f = find("pmc_%s/**/*counter_collection.csv" % tag)
     if not f:
         continue
@@ -42,30 +42,36 @@ for tag in ("fetch", "write", "sq", "sq2", "ea", "l2"):
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
     pmc[tag] = {k: dict({"dispatches": len(n[k])}, **{c: v / len(n[k]) for c, v in agg[k].items()}) for k in agg}
 json.dump(pmc, open(os.path.join(dst, R + "_pmc_per_dispatch.json"), "w"), indent=1)
-ks = [k for k in pmc["fetch"] if k.startswith("k_step")][0]
+merged = any(k.startswith("k_cycle") for k in pmc["fetch"])
+ks = [k for k in pmc["fetch"] if k.startswith("k_cycle" if merged else "k_step")][0]
 fk, wk = pmc["fetch"][ks]["FETCH_SIZE"], pmc["write"][ks]["WRITE_SIZE"]
-kd = [k for k in pmc["fetch"] if k.startswith("k_deal")][0]
 import bench as bench_py  # (module level only defines functions and constants)
 traffic = {
-    "kernel_source_sha256": bench_py.kernel_source_sha256(),  # bench.py reports this traffic only for these very sources
+    "kernel_source_sha256": bench_py.kernel_source_sha256(),  # bench.py reports this traffic only for these very sources ...
     "kernel_sources": list(bench_py.KERNEL_SOURCES),
+    "shape": tb["roofline"]["launch_shape"],                  # ... and this very launch shape
+    "kernel": ks,
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/refresh_profiles.sh), bench.py --steps 30 "
-              "--warmup 10, 65536 x 3-player games, per k_step dispatch (88 lockstep iterations)",
+              "--warmup 10, per dispatch of the dominant kernel (one dealing cycle: k_cycle holds the step AND the dealing wavefronts)",
     "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
     "note": "gfx950: FETCH_SIZE counts half of a wide coalesced 16 B/lane stream (MI355X_MICROARCH.md, HBM) -> doubled; "
             "WRITE_SIZE is exact for 16 B/lane stores",
     "k_step_bytes_per_launch": int(round((2 * fk + wk) * 1024)),
     "uncorrected_bytes_per_launch": int(round((fk + wk) * 1024)),
-    "k_deal_bytes_per_launch_uncorrected": int(round((pmc["fetch"][kd]["FETCH_SIZE"] + pmc["write"][kd]["WRITE_SIZE"]) * 1024)),
 }
-if "ea" in pmc:  # the dealing kernel at the fabric: read requests by size (nearly all 128-byte lines), write requests (64-byte and smaller)
-    e = pmc["ea"][kd]
+if "ea" in pmc and ks in pmc["ea"]:  # the same kernel at the fabric: read requests by size (nearly all 128-byte lines), write requests (64-byte and smaller)
+    e = pmc["ea"][ks]
     rd128, rd, wr64, wr = e["TCC_EA0_RDREQ_128B_sum"], e["TCC_EA0_RDREQ_sum"], e["TCC_EA0_WRREQ_64B_sum"], e["TCC_EA0_WRREQ_sum"]
-    traffic["k_deal_fabric"] = {
+    traffic["fabric"] = {
         "read_requests": rd, "read_requests_128B": rd128, "write_requests": wr, "write_requests_64B": wr64,
         "read_bytes": int(rd128 * 128 + (rd - rd128) * 64), "write_bytes": int(wr64 * 64 + (wr - wr64) * 32),
-        "note": "per dealing run (k_deal dispatch): TCC_EA0_RDREQ[_128B] / TCC_EA0_WRREQ[_64B]; reads that are not 128-byte "
-                "requests counted as 64 bytes, writes that are not 64-byte requests as 32 bytes"}
+        "note": "per dispatch: TCC_EA0_RDREQ[_128B] / TCC_EA0_WRREQ[_64B]; reads that are not 128-byte requests counted as 64 bytes, "
+                "writes that are not 64-byte requests as 32 bytes"}
+    if not merged:
+        kd = [k for k in pmc["ea"] if k.startswith("k_deal")][0]
+        e = pmc["ea"][kd]
+        traffic["k_deal_fabric"] = {"read_bytes": int(e["TCC_EA0_RDREQ_128B_sum"] * 128 + (e["TCC_EA0_RDREQ_sum"] - e["TCC_EA0_RDREQ_128B_sum"]) * 64),
+                                    "write_bytes": int(e["TCC_EA0_WRREQ_64B_sum"] * 64 + (e["TCC_EA0_WRREQ_sum"] - e["TCC_EA0_WRREQ_64B_sum"]) * 32)}
 json.dump(traffic, open(os.path.join(dst, R + "_hbm_traffic.json"), "w"), indent=1)
 # config 5
 c5 = os.path.join(src, "cfg5.json")

@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 python3 bench.py --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 "$root/bench.py" --steps 100 --warmup 10 --blocks 2 --no-cpu-baseline --no-other-configs > "$out/trace_bench.json" 2> "$out/trace.err"; echo "trace rc=$?"
-for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "sq2 SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS" "ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "l2 TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum TCC_MISS_sum"; do
+for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "sq2 SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS" "ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "l2 TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum TCC_MISS_sum" "issue SQ_WAIT_INST_ANY SQ_IFETCH SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"; do
   set -- $pass; tag=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/pmc_$tag" -- python3 "$root/bench.py" --steps 30 --warmup 10 --blocks 1 --no-cpu-baseline --no-other-configs > "$out/pmc_$tag.json" 2> "$out/pmc_$tag.err"; echo "pmc $tag rc=$?"
 done
