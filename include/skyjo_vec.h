@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SKYJO_ABI_VERSION 3
+#define SKYJO_ABI_VERSION 4
 #define SKYJO_MAX_PLAYERS 12 /* skyjo.py:24-26 */
 #define SKYJO_NUM_ACTIONS 26 /* skyjo.py:46 */
 #define SKYJO_NUM_CARDS 150  /* skyjo.py:80 */

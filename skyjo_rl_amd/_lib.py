@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SKYJO_LIB") or os.path.join(_HERE, "libskyjo_vec.so")  # SKYJO_LIB: diagnostic builds
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_PLAYERS = 12
 ST_OK, ST_ILLEGAL, ST_NOOP_DONE, ST_RESET, ST_ERROR = 0, 1, 2, 3, 4
 RNG_MT19937, RNG_PHILOX = 0, 1

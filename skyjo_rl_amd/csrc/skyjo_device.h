@@ -1456,16 +1456,6 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
   HDR_FLUSH(h);
   tile_store_nt(P, P.state, tile, lane, lp);
   if (!POLICY && raw_out && valid) sk_export_raw(P, lp, g, raw_out + (size_t)g * raw_stride);
-  if (!POLICY) {
-    sk_error_to_host(P, lane);
-    if (P.host_seq) {
-      // ONE tile = this wavefront is the whole launch: everything the host reads back (records, exported games, error word)
-      // has been stored by it - make that visible system-wide, then tell the host, which is spinning on the word instead of
-      // paying for a stream synchronisation (skyjo_vec_step_host)
-      __threadfence_system();
-      if (lane == 0) __hip_atomic_store(&P.health_host[3], P.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
   if (P.ov_flags & 2u) {
     // (first what the run beside THIS launch has dealt: a game whose busy mark outlived the launch in which it is dealt would
     // get a new episode only every second run.  The dealing kernel was started before this launch and is as good as through:
@@ -1476,6 +1466,18 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
       sk_publish_deals(P, g);
     }
     sk_plan_deals(P, g, lane);
+  }
+  // (after the way out: its wait for the run beside this launch can be what raises the error - ADVICE r3's test found a host call
+  // that came back clean with the word already set)
+  if (!POLICY) {
+    sk_error_to_host(P, lane);
+    if (P.host_seq) {
+      // ONE tile = this wavefront is the whole launch: everything the host reads back (records, exported games, error word)
+      // has been stored by it - make that visible system-wide, then tell the host, which is spinning on the word instead of
+      // paying for a stream synchronisation (skyjo_vec_step_host)
+      __threadfence_system();
+      if (lane == 0) __hip_atomic_store(&P.health_host[3], P.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   // per-wavefront event counts go to the tile's own slot: thousands of same-address atomics at the
   // end of a launch would serialise at ~12 ns each (MI355X_MICROARCH.md, "fanin")
