@@ -1784,10 +1784,11 @@ struct MtChunkStream {
     base = live ? c : base, pos = live ? 0 : pos, chunks_made += live ? 1 : 0;
     gen = live ? (c + 16 == 624 ? 0 : c + 16) : c;
     const uint32_t lm = live ? 0xffffffffu : 0u;  // (a select the compiler cannot turn into a branch around the tempering)
-#pragma unroll
 #ifdef SK_EXP_DEAL_NO_TEMPER  // timing build: six vector instructions fewer per output
+#pragma unroll
     for (int k = 0; k < 16; k++) R[k] = __builtin_amdgcn_bitop3_b32(R[k], v[k], lm, 0xd8);
 #else
+#pragma unroll
     for (int k = 0; k < 16; k++) R[k] = __builtin_amdgcn_bitop3_b32(R[k], mt_temper3(v[k]), lm, 0xd8);
 #endif
 #ifdef SK_EXP_DEAL_NO_STORES  // timing build: the regenerated chunk is not written back
