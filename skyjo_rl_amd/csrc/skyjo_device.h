@@ -9,8 +9,15 @@
 // time - scoring a finished game, re-dealing it - is where the other 62 wait: the scoring is deferred
 // and batched (SK_SCORE_EVERY), the re-deal overlaps its memory round trip with the live lanes' step.
 //
-// Diagnostic builds (tools/dev/): -DSK_STAMPS (section cycle counters), -DSK_EXP_NO_SCORE / _NO_RARE /
-// _NO_DMA / _NO_DRAIN / _REC_WRAP (leave a piece out and time the rest; results are then wrong on purpose).
+// Kernels: k_step (the body below, one wavefront per workgroup: caller-action steps, and the fused rollout of the engines k_cycle
+// does not cover), k_deal (the dealing run on its own), and k_cycle - the default for the fused rollout: ONE launch per dealing
+// cycle whose workgroups hold step AND dealing wavefronts of the same games, so that a dealt episode changes hands inside a CU
+// (workgroup-scope release / acquire instead of an L2 write-back / invalidation per wavefront: see k_cycle).
+//
+// Diagnostic builds (tools/dev/): -DSK_STAMPS (section cycle counters), -DSK_TRACE (placement, time span and clock of every
+// wavefront), -DSK_EXP_NO_SCORE / _NO_RARE / _NO_FENCE / _REC_WRAP / _DEAL_NO_LOADS / _DEAL_NO_STORES / _DEAL_NO_PARTNERS /
+// _DEAL_NO_DECK / _DEAL_NO_TEMPER / _CYCLE_SYNTH (leave a piece out or put a synthetic one in and time the rest; results are then
+// wrong on purpose - EXPERIMENTS.md says what each of them showed).
 //
 // Semantics follow rlskyjo/game/skyjo.py and rlskyjo/environment/skyjo_env.py; each function
 // cites the lines it restates.  Nothing here shares code with oracle/.
@@ -1137,7 +1144,8 @@ __device__ __forceinline__ bool deal_inline(const SkParams &P, uint8_t *lp, uint
 // SKYJO_ACTION_SKIP as a caller action leaves the game exactly as it is (no step, no reset; its record is still
 // written): that is how the single-game views step ONE game of a shared engine.
 // ------------------------------------------------------------------------------------------
-// Pipelined dealing beside the step kernel (small batches): the step kernel does the bank bookkeeping
+// Pipelined dealing beside the step wavefronts - between two kernels on two streams, or between the wavefronts of one k_cycle
+// workgroup, the protocol is the same: the step kernel does the bank bookkeeping
 // of its own games itself - lane = game - so that a dealing cycle is ONE launch on the caller's stream and nothing on that
 // stream ever waits for the dealing stream:
 //   on the way out of the launch after which a run is due   sk_plan_deals    what k_scan does, minus the work list: the

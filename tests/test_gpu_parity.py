@@ -167,7 +167,10 @@ def test_step_vs_oracle_random_actions(N, ind, rng_mode, B):
 
 
 @pytest.mark.parametrize("N,ind,rng_mode,B", [(3, True, 0, 4096), (2, True, 0, 4096), (4, True, 1, 2048),
-                                              (3, False, 1, 777), (12, True, 0, 128)])
+                                              (3, False, 1, 777), (12, True, 0, 128),
+                                              # k_cycle with two / three step wavefronts per workgroup and a last workgroup that is not full
+                                              # (258 tiles -> S = 2, 129 workgroups; 626 tiles -> S = 3, 209 workgroups, the last with two tiles)
+                                              (3, True, 0, 16500), (2, True, 0, 40010)])
 def test_rollout_vs_oracle(N, ind, rng_mode, B):
     """Fused K-step rollout kernel with the on-device policy vs the oracle's restatement of it."""
     import torch
@@ -178,12 +181,12 @@ def test_rollout_vs_oracle(N, ind, rng_mode, B):
     ora = _oracle_vec(num_envs=B, game_id0=1000, **cfg)
     eng.seed(None, 99)
     ora.seed(None, 99)
-    K, rounds = 40, 12 if N <= 4 else 30
+    K, rounds = 40, (12 if B <= 4096 else 8) if N <= 4 else 30
     for r in range(rounds):
         rec = eng.new_records(K)
         act = torch.empty((K, B), dtype=torch.int32, device="cuda")
         eng.rollout(K, policy_seed=4242, records=rec, actions=act)
-        oact = ora.rollout(K, 4242, record_actions=True)
+        oact = ora.rollout(K, 4242, record_actions=True, threads=8 if B > 4096 else 1)
         np.testing.assert_array_equal(act.cpu().numpy(), oact, err_msg=f"actions round {r}")
         last = eng.split(rec[K - 1])
         obs, mask, agent, phase = ora.observe()
