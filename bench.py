@@ -55,6 +55,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (the guide's figure without sparsity)
 CHUNK = int(os.environ.get("SKYJO_BENCH_CHUNK", "0"))  # lockstep iterations per kernel launch; 0 = the engine's dealing interval
+CYCLES_PER_LAUNCH = int(os.environ.get("SKYJO_BENCH_CYCLES", "8"))  # dealing cycles per launch of the one-kernel form (k_cycle)
 SETTLE = int(os.environ.get("SKYJO_BENCH_SETTLE", "100"))  # launches between seeding and the warm-up (see main)
 # the reference's own Python loop (core loop + policy_ra, N = 3, indirect observation), measured in the
 # build container (8-core Xeon 2.1 GHz); the reference cannot travel to the GPU box, so these are constants
@@ -184,12 +185,13 @@ def side_rollout_config(name, B, N, steps, warmup, device, rng_mode, indirect=Tr
     eng = SkyjoVecEnv(B, num_players=N, observe_other_player_indirect=indirect, device=device, rng_mode=rng_mode, game_id0=game_id0,
                       **ENV_CFG)
     eng.seed(None, 0)
-    chunk = eng.deal_interval()
+    mult = CYCLES_PER_LAUNCH if eng.dealing_form() == "one kernel" else 1  # (k_cycle: several dealing cycles per launch)
+    chunk = eng.deal_interval() * mult
     rec = eng.new_records(chunk)
     sync = torch.cuda.synchronize
     for _ in range(settle + warmup):
         eng.rollout(chunk, policy_seed=1, records=rec)
-    chunk2 = eng.deal_interval()  # (the interval adapts itself while the banks settle)
+    chunk2 = eng.deal_interval() * mult  # (the interval adapts itself while the banks settle)
     if chunk2 != chunk:
         chunk = chunk2
         rec = eng.new_records(chunk)
@@ -345,7 +347,9 @@ def main():
     assert eng.num_envs == B and eng.game_id0 == rank * B
     eng.seed(None, 0)
     global CHUNK
-    CHUNK = min(CHUNK, eng.deal_interval()) if CHUNK > 0 else eng.deal_interval()  # one launch per dealing cycle
+    CHUNK = min(CHUNK, eng.deal_interval()) if CHUNK > 0 else eng.deal_interval()  # one launch per dealing cycle ...
+    if eng.dealing_form() == "one kernel" and CYCLES_PER_LAUNCH > 1:
+        CHUNK = eng.deal_interval() * CYCLES_PER_LAUNCH  # ... or ONE launch of k_cycle over several (the tiles stay in LDS between them)
     D = eng.obs_dim
     record = not args.no_records
     rec = eng.new_records(CHUNK) if record else None           # [CHUNK, B, 64] ring reused by every launch

@@ -159,8 +159,11 @@ int skyjo_vec_reset(skyjo_vec *h, const uint8_t *mask, void *records_out, void *
  * of every game, then the observation of the next expected player.  actions: int32[num_envs]. */
 int skyjo_vec_step(skyjo_vec *h, const int32_t *actions, void *records_out, void *stream);
 
-/* `iters` lockstep iterations in one launch with the uniform random admissible policy
- * (rlskyjo/models/random_admissible_policy.py:6-28) evaluated on device.
+/* `iters` lockstep iterations with the uniform random admissible policy (rlskyjo/models/random_admissible_policy.py:6-28)
+ * evaluated on device.  The call is cut into launches at the dealing cadence (SKYJO_OPT_DEAL_INTERVAL); in the one-kernel
+ * form (SKYJO_OPT_OVERLAP 3) up to 16 whole dealing cycles share ONE launch when the call asks for that many iterations at
+ * once - the games' tiles then stay in LDS across the cycle ends (65 536 x 3: 37 -> 44 x 10^9 env-steps/s from 64 to 512+
+ * iterations per call).  Results do not depend on how a caller slices its iterations into calls.
  * records_out: NULL, or [iters][num_envs][record_bytes] (record AFTER each iteration);
  * actions_out: NULL, or int32[iters][num_envs] (-1 where no action was applied) - the same value is byte D of every
  * record, so a caller that keeps the records does not need this array. */

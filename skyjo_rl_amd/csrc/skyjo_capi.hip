@@ -47,6 +47,7 @@ struct DevGuard {
 #define GUARD(h) DevGuard guard_((h)->cfg.device_id)
 
 constexpr int kMaxRolloutChunk = 128;  // lockstep iterations per k_step launch (the tile stays in LDS for a whole launch)
+constexpr int kMaxCyclesPerLaunch = 16;  // k_cycle: whole dealing cycles per launch (each of deal_every_iters iterations)
 // Default number of lockstep iterations between two dealing runs.  A run adds one episode to every bank that is not
 // full, so the interval has to stay below the mean episode length of the policy in use (random admissible policy:
 // 76 / 105 / 134 steps for 2 / 3 / 4 players) or the banks of SK_BANK episodes drain and finished games deal in
@@ -362,7 +363,8 @@ int start_deals_piped(skyjo_vec *h, hipStream_t s) {
 }
 
 int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions, uint8_t *rec, int32_t *act_out,
-                int iters, uint64_t policy_seed, double *end_rew = nullptr, uint8_t *end_flag = nullptr, uint8_t *raw_out = nullptr) {
+                int iters, uint64_t policy_seed, double *end_rew = nullptr, uint8_t *end_flag = nullptr, uint8_t *raw_out = nullptr,
+                int cycle_len = 0) {
   h->raw_valid = false;  // (the host's copy of the games is stale from here on; step_host sets it again)
   dim3 grid(h->P.tiles), block(SK_TILE);
   const bool ind = h->P.L.indirect != 0;
@@ -379,7 +381,7 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
     dim3 cgrid((h->P.tiles + S - 1) / S), cblock(2 * S * SK_TILE);
 #define LAUNCHC(NP)                                                                                                                       \
   hipExtLaunchKernelGGL((k_cycle<true, NP>), cgrid, cblock, (uint32_t)h->lds_cycle, s, e0, e1, 0, h->P, rec, act_out, iters, policy_seed, \
-                        h->iter, tag, (uint32_t)h->lds_rollout, lds_deal)
+                        h->iter, tag, (uint32_t)h->lds_rollout, lds_deal, cycle_len)
     switch (h->P.L.N) {
       case 2: LAUNCHC(2); break;
       case 3: LAUNCHC(3); break;
@@ -903,8 +905,21 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
     const int due = h->deal_every_iters - h->pending_iters;
     if (n > due) n = due > 0 ? due : 1;
     const bool run_due = h->pending_iters + n >= h->deal_every_iters, piped = piped_mode(h);
-    if (run_due && piped) plan_cycle(h);
-    int rc = launch_step(h, s, true, nullptr, rec, actions_out, n, policy_seed);
+    // The one-kernel form keeps its tiles in LDS over several dealing cycles when the caller asks for that many iterations at once:
+    // up to kMaxCyclesPerLaunch whole cycles in ONE launch (the cycle ends inside it are handled by the kernel: step_body, k_cycle)
+    int cycles = 1;
+    if (h->merged && run_due && h->pending_iters == 0 && h->P.L.indirect && !getenv("SKYJO_NO_MULTI_CYCLE")) {
+      cycles = (iters - done) / h->deal_every_iters;
+      cycles = cycles < 1 ? 1 : (cycles > kMaxCyclesPerLaunch ? kMaxCyclesPerLaunch : cycles);
+      n = cycles * h->deal_every_iters;
+    }
+    if (run_due && piped) {
+      plan_cycle(h);
+      const uint32_t first = h->deal_tag;  // the id of the first run planned by this launch; the kernel counts on from it
+      for (int c = 1; c < cycles; c++) next_deal_tag(h, false);
+      h->P.plan_new_tag = first;
+    }
+    int rc = launch_step(h, s, true, nullptr, rec, actions_out, n, policy_seed, nullptr, nullptr, nullptr, cycles > 1 ? h->deal_every_iters : 0);
     if (rc) return rc;
     done += n;
     if (run_due && (rc = piped ? start_deals_piped(h, s) : start_deals(h, s))) return rc;

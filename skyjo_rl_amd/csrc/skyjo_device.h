@@ -1231,10 +1231,17 @@ __device__ __forceinline__ void sk_export_raw(const SkParams &P, uint8_t *lp, in
 
 // The body of the step kernel for ONE wavefront: tile `tile`, its lanes 0..63, its own LDS region `lds_raw` (k_step: the
 // workgroup IS that wavefront; k_cycle: four such wavefronts share a workgroup with four dealing wavefronts).
+// `cycle_len` != 0 (k_cycle only): the launch spans several dealing cycles of that many iterations - at every cycle end inside the
+// launch the wavefront does what the way out of a launch does (publish the run beside it, plan the next) and meets the dealing
+// wavefronts of its workgroup at a barrier, after which they deal the run just planned; the tile never leaves LDS.
+__device__ __forceinline__ uint32_t sk_next_tag(uint32_t t) {
+  t = (t + 1u) & 0x7fffffffu;
+  return t ? t : 1u;
+}
 template <bool INDIRECT, bool POLICY, int NP>
 __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, const int lane, uint32_t *lds_raw, const int32_t *actions,
                                           uint8_t *rec_out, int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0,
-                                          double *end_rew_out, uint8_t *end_out, uint8_t *raw_out, int raw_stride) {
+                                          double *end_rew_out, uint8_t *end_out, uint8_t *raw_out, int raw_stride, const int cycle_len = 0) {
   SkParams P = Pin;
   TRACE_DECL;
   if (NP > 0) P.L = sk_make_layout(NP, INDIRECT ? 1 : 0);  // same values as the host computed, now constants
@@ -1459,6 +1466,13 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
           if (16 * j + (lane >> 2) < live)
             __builtin_nontemporal_store((u32x4_t){v[j].x, v[j].y, v[j].z, v[j].w}, (u32x4_t *)(blk + j * 1024 + lane * 16));
       }
+    }
+    if (POLICY && cycle_len && it + 1 < iters && (it + 1) % cycle_len == 0) {  // (wavefront-uniform) a dealing cycle ends inside the launch
+      if (P.busy[g]) (void)wait_deal_done(P, g);
+      sk_publish_deals(P, g);
+      sk_plan_deals(P, g, lane);
+      P.plan_new_tag = sk_next_tag(P.plan_new_tag);
+      __syncthreads();  // k_cycle: the dealing wavefronts of this workgroup take the run just planned from here
     }
   }
   HDR_FLUSH(h);
@@ -2449,7 +2463,7 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
 template <bool INDIRECT, int NP>
 __global__ __launch_bounds__(2 * SK_CYCLE_MAX_S *SK_TILE) void k_cycle(SkParams Pin, uint8_t *rec_out, int32_t *act_out, int iters, uint64_t policy_seed,
                                                                         uint64_t iter0, uint32_t deal_tag_run, uint32_t lds_step_bytes,
-                                                                        uint32_t lds_deal_bytes) {
+                                                                        uint32_t lds_deal_bytes, int cycle_len) {
   extern __shared__ uint32_t lds_raw[];
   const uint32_t S = blockDim.x >> 7;  // step (= dealing) wavefronts per workgroup
   const uint32_t split = lds_deal_bytes >> 30;  // (diagnostic role splits, see below)
@@ -2478,7 +2492,7 @@ __global__ __launch_bounds__(2 * SK_CYCLE_MAX_S *SK_TILE) void k_cycle(SkParams 
   Pin.wg_local = 1u;  // the games of tile `unit` are dealt by dealing slot `slot` of THIS workgroup: hand-overs stay inside the CU
   if (role == 0) {
     step_body<INDIRECT, true, NP>(Pin, unit, lane, lds_raw + (size_t)slot * (lds_step_bytes >> 2), nullptr, rec_out, act_out, iters, policy_seed, iter0,
-                                  nullptr, nullptr, nullptr, 0);
+                                  nullptr, nullptr, nullptr, 0, cycle_len);
 #ifdef SK_EXP_CYCLE_SYNTH  // diagnostic: the second wavefront of every SIMD runs a synthetic stream of vector instructions instead
   } else {
     uint32_t x = (uint32_t)lane * 2654435761u + (uint32_t)unit, y = x ^ 0x9e3779b9u;
@@ -2502,10 +2516,22 @@ __global__ __launch_bounds__(2 * SK_CYCLE_MAX_S *SK_TILE) void k_cycle(SkParams 
 #endif
     if (x == 0x12345678u && y == 1u) Pin.stamps[0] = x;  // (keeps the stream alive)
 #else
-  } else if (deal_tag_run) {
+  } else {
+    // the run the previous launch planned (deal_tag_run, 0 = none), then - a launch of several dealing cycles - the runs its step
+    // wavefronts plan at the cycle ends inside it: ids plan_new_tag, + 1, ... (the last one is left to the next launch)
     SkParams P = Pin;
-    P.deal_tag = deal_tag_run;
-    deal_body<NP>(P, 0, 3, unit, lane, lds_raw + (((size_t)S * lds_step_bytes + (size_t)slot * lds_deal_bytes) >> 2));
+    const int cycles = cycle_len > 0 ? (iters + cycle_len - 1) / cycle_len : 1;
+    uint32_t tag = deal_tag_run, planned = Pin.plan_new_tag;
+    for (int c = 0; c < cycles; c++) {
+      if (tag) {
+        P.deal_tag = tag;
+        deal_body<NP>(P, 0, 3, unit, lane, lds_raw + (((size_t)S * lds_step_bytes + (size_t)slot * lds_deal_bytes) >> 2));
+      }
+      if (c + 1 < cycles) {
+        __syncthreads();  // (the step wavefronts arrive when they have planned the next run)
+        tag = planned, planned = sk_next_tag(planned);
+      }
+    }
 #endif
   }
 }
