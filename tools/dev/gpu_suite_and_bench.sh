@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-root=$PWD; out=$root/gpurun_out/r4c11; mkdir -p "$out"
+root=$PWD; out=$root/gpurun_out/suite; mkdir -p "$out"
 timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q > "$out/pytest.log" 2>&1; echo "pytest rc=$?"
 tail -n 8 "$out/pytest.log"
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?"
