@@ -604,7 +604,9 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     h->merged_capable = fits;
     if (fits) {
       const void *fn = cfg->num_players == 2 ? (const void *)k_cycle<true, 2> : cfg->num_players == 3 ? (const void *)k_cycle<true, 3> : (const void *)k_cycle<true, 4>;
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need) != hipSuccess) {
+      // (the attribute belongs to the function, not to the handle: always the whole CU, so that engines of different batch sizes -
+      // different S - can live side by side in one process)
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
         (void)hipGetLastError();
         h->merged_capable = false;
       }

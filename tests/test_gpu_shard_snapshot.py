@@ -321,3 +321,29 @@ def test_config4_all_eight_shards_equal_one_262144_game_engine():
     np.testing.assert_allclose(tot["sum_reward"], cb["sum_reward"], rtol=1e-12)
     np.testing.assert_allclose(tot["sum_reward_sq"], cb["sum_reward_sq"], rtol=1e-12)
     assert abs(tot["mean_episode_len"] - cb["sum_len"] / cb["episodes"]) < 1e-12
+
+
+def test_engines_of_different_shapes_side_by_side_in_one_process():
+    """The one-kernel form sizes its workgroups by the batch (S = 1 .. 4 step + dealing wavefronts, up to 159 KB of dynamic LDS):
+    engines of different sizes alive at the same time, launched alternately, each equal to its oracle."""
+    from oracle import skyjo_oracle as so
+
+    shapes = [(65536, 3), (4096, 2), (20000, 3), (40000, 4)]
+    engs, oras = [], []
+    for B, N in shapes:
+        cfg = dict(CFG, num_players=N)
+        e = _engine(B, **cfg)
+        assert e.dealing_form() == "one kernel"
+        e.seed(None, 9)
+        o = so.OracleVec(num_envs=B, **cfg)
+        o.seed(None, 9)
+        engs.append(e), oras.append(o)
+    import torch
+    for r in range(3):
+        for (B, N), e, o in zip(shapes, engs, oras):
+            K = 2 * e.deal_interval() if r == 1 else 48
+            act = torch.empty((K, B), dtype=torch.int32, device="cuda")
+            e.rollout(K, policy_seed=5, actions=act)
+            np.testing.assert_array_equal(act.cpu().numpy(), o.rollout(K, 5, threads=16, record_actions=True), err_msg=f"{B} x {N}, round {r}")
+    for e in engs:
+        e.close()
