@@ -34,8 +34,8 @@ Extra objects on the same line:
   episode_stats  what the ranks all-gather (RCCL): per-seat reward / score statistics
   other_configs  (N = 1) short blocks of the other BASELINE.json configurations in the same run: cfg2 (4 096 x 2),
                  the cfg4 shard (32 768 x 3, game_id0 = 3 * 32 768), cfg5 (65 536 x 4, the action-mask model's policy +
-                 value net in the loop, float32-grade and bf16), the counter-based RNG mode (also at 98 304 games: 1.5 step
-                 wavefronts per SIMD), the direct observation
+                 value net in the loop, float32-grade and bf16), the counter-based RNG mode (also at 131 072 games: two
+                 rounds of workgroups), the direct observation
   cpu_baseline   the CPU oracle (oracle/, a port of the reference's algorithm) timed on host cores, with
                  speedup_vs_cpu_port and speedup_vs_reference_constant beside it
 """
@@ -274,8 +274,8 @@ def other_configs(device, steps, warmup):
             ("cfg5_65536x4_model_bf16", lambda: side_model_config("bf16", 65536, 4, 64, 7, device)),
             ("philox_65536x3", lambda: side_rollout_config("philox", 65536, 3, steps, warmup, device, RNG_PHILOX)),
             ("direct_obs_65536x3", lambda: side_rollout_config("direct", 65536, 3, steps, warmup, device, RNG_MT19937, indirect=False)),
-            # more games than the metric's batch: six step wavefronts of 25 KB LDS per CU, 1.5 per SIMD - latency hidden by occupancy
-            ("philox_98304x3", lambda: side_rollout_config("philox98k", 98304, 3, steps, warmup, device, RNG_PHILOX))):
+            # twice the metric's batch: two rounds of k_cycle workgroups (a workgroup's LDS fills its CU)
+            ("philox_131072x3", lambda: side_rollout_config("philox131k", 131072, 3, steps, warmup, device, RNG_PHILOX))):
         try:
             out[name] = fn()
         except Exception as e:  # a side configuration must not take the headline line down with it

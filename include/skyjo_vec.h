@@ -248,12 +248,13 @@ int skyjo_vec_debug_trace(skyjo_vec *h, uint64_t *out_host);
  *   0  in line on the caller's stream, after the step launch that makes it due;
  *   2  the two-stream form: the dealing kernel on a stream of its own beside the step kernels that follow (its episodes are
  *      published one dealing cycle later; the step kernel plans and publishes the runs itself, nothing on the caller's
- *      stream waits for the dealing stream).  Default for batches that leave SIMDs idle (at most 768 tiles of 64 games);
+ *      stream waits for the dealing stream).  Default, for batches that leave SIMDs idle (at most 768 tiles of 64 games), of
+ *      the engines form 3 does not cover;
  *   3  the one-kernel form (k_cycle): every workgroup is one CU's worth of wavefronts, one step and one dealing wavefront per
  *      SIMD, the dealing wavefronts work for the games of their own workgroup - the hand-over never leaves the CU, so it needs
  *      no L2 write-back / invalidation.  Two to four players, indirect observation; S = 1 .. 4 step and as many dealing wavefronts
  *      per workgroup, whichever spreads the batch over the CUs (their LDS regions must fit 160 KB: four players up to S = 3).
- *      Default on a full chip (more than 768 tiles); the fused rollout only - other calls deal as in form 0;
+ *      The default wherever it exists; the fused rollout only - other calls deal as in form 0;
  *   1  "beside the step kernel" in whichever of the two forms the engine prefers.
  * skyjo_vec_get_option returns 0, 2 or 3.  Environment overrides: SKYJO_OVERLAP (0 / 1), SKYJO_MERGED (0 / 1: prefer form 3). */
 #define SKYJO_OPT_OVERLAP 2

@@ -613,9 +613,10 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     }
     // Default: the one-kernel form wherever it fits (measured at 4 096 .. 65 536 games and two to four players: + 9 .. 32 % over the
     // two-stream form, + 18 .. 57 % over dealing in line, EXPERIMENTS.md round 4); SKYJO_MERGED=0 falls back to the older forms.
-    // (Batches beyond four tiles per CU would need a second round of workgroups - a workgroup's LDS fills its CU - where the in-line
-    // form simply runs six step wavefronts per CU: 98 304 x 3, counter-based deals: 34.5 against 39.8.)
-    h->prefer_merged = P.tiles <= SK_CYCLE_MAX_S * ncu;
+    // (Batches beyond four tiles per CU run in two or more rounds of workgroups - a workgroup's LDS fills its CU: 98 304 x 3 29.1
+    // against 23.8 in line, 131 072 x 3 34.0 against 21.0; counter-based deals 37.5 / 49.4 against 39.6 / 32.5: the one-kernel
+    // form still wins everywhere but at one and a half rounds of counter-based deals.)
+    h->prefer_merged = true;
     if (const char *e = getenv("SKYJO_MERGED")) h->prefer_merged = atoi(e) != 0;
     h->merged = h->merged_capable && h->prefer_merged && !getenv("SKYJO_OVERLAP");
     if (h->merged) h->overlap = false;  // (no second stream in this form)
