@@ -372,20 +372,23 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
   hipEvent_t e0, e1;
   if ((rc = prof_events(h, 0, &e0, &e1))) return rc;
   if (h->deal_inflight && h->inflight_piped) h->P.ov_flags |= 1u;  // publish what has been dealt since (sk_publish_deals)
-  if (h->merged && policy && ind && !end_rew && !raw_out) {
+  if (h->merged && policy && !end_rew && !raw_out) {
     // one kernel for the whole dealing cycle: S step + S dealing wavefronts per workgroup (= per CU)
     uint32_t lds_deal = SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE), tag = h->cycle_deal_tag;
     h->cycle_deal_tag = 0;
     if (const char *e = getenv("SKYJO_CYCLE_SPLIT")) lds_deal |= (uint32_t)(atoi(e) & 3) << 30;  // diagnostic: 1 = roles by SIMD parity, 2 = by SIMD pair
     const int S = h->cycle_s;
     dim3 cgrid((h->P.tiles + S - 1) / S), cblock(2 * S * SK_TILE);
-#define LAUNCHC(NP)                                                                                                                       \
-  hipExtLaunchKernelGGL((k_cycle<true, NP>), cgrid, cblock, (uint32_t)h->lds_cycle, s, e0, e1, 0, h->P, rec, act_out, iters, policy_seed, \
+#define LAUNCHC(I, NP)                                                                                                                 \
+  hipExtLaunchKernelGGL((k_cycle<I, NP>), cgrid, cblock, (uint32_t)h->lds_cycle, s, e0, e1, 0, h->P, rec, act_out, iters, policy_seed, \
                         h->iter, tag, (uint32_t)h->lds_rollout, lds_deal, cycle_len)
-    switch (h->P.L.N) {
-      case 2: LAUNCHC(2); break;
-      case 3: LAUNCHC(3); break;
-      default: LAUNCHC(4); break;
+    switch (h->P.L.N * 2 + (ind ? 1 : 0)) {
+      case 5: LAUNCHC(true, 2); break;
+      case 7: LAUNCHC(true, 3); break;
+      case 9: LAUNCHC(true, 4); break;
+      case 4: LAUNCHC(false, 2); break;
+      case 6: LAUNCHC(false, 3); break;
+      default: LAUNCHC(false, 4); break;
     }
 #undef LAUNCHC
     HIPCHK(hipGetLastError());
@@ -598,12 +601,16 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     int S = (P.tiles + ncu - 1) / ncu;
     S = S < 1 ? 1 : (S > SK_CYCLE_MAX_S ? SK_CYCLE_MAX_S : S);
     if (const char *e = getenv("SKYJO_CYCLE_S")) S = atoi(e) >= 1 && atoi(e) <= SK_CYCLE_MAX_S ? atoi(e) : S;
-    const size_t need = (size_t)S * (h->lds_rollout + (size_t)SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE)) + 32;
-    const bool fits = fixed_n && P.L.indirect && need <= 160 * 1024 && !getenv("SKYJO_LDS_PAD");
+    const size_t per_s = h->lds_rollout + (size_t)SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE);
+    const int natural_s = S;
+    while (S > 1 && (size_t)S * per_s + 32 > 160 * 1024) S--;  // (the wider records of the direct observation, four players: fewer wavefronts per workgroup, more workgroups)
+    const size_t need = (size_t)S * per_s + 32;
+    const bool fits = fixed_n && need <= 160 * 1024 && !getenv("SKYJO_LDS_PAD");
     h->lds_cycle = need, h->cycle_s = S;
     h->merged_capable = fits;
     if (fits) {
-      const void *fn = cfg->num_players == 2 ? (const void *)k_cycle<true, 2> : cfg->num_players == 3 ? (const void *)k_cycle<true, 3> : (const void *)k_cycle<true, 4>;
+      const void *fn = P.L.indirect ? (cfg->num_players == 2 ? (const void *)k_cycle<true, 2> : cfg->num_players == 3 ? (const void *)k_cycle<true, 3> : (const void *)k_cycle<true, 4>)
+                                    : (cfg->num_players == 2 ? (const void *)k_cycle<false, 2> : cfg->num_players == 3 ? (const void *)k_cycle<false, 3> : (const void *)k_cycle<false, 4>);
       // (the attribute belongs to the function, not to the handle: always the whole CU, so that engines of different batch sizes -
       // different S - can live side by side in one process)
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -615,8 +622,10 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     // two-stream form, + 18 .. 57 % over dealing in line, EXPERIMENTS.md round 4); SKYJO_MERGED=0 falls back to the older forms.
     // (Batches beyond four tiles per CU run in two or more rounds of workgroups - a workgroup's LDS fills its CU: 98 304 x 3 29.1
     // against 23.8 in line, 131 072 x 3 34.0 against 21.0; counter-based deals 37.5 / 49.4 against 39.6 / 32.5: the one-kernel
-    // form still wins everywhere but at one and a half rounds of counter-based deals.)
-    h->prefer_merged = true;
+    // form still wins everywhere but at one and a half rounds of counter-based deals.  Not so where the LDS - not the batch - makes
+    // the workgroups smaller than a CU's share of the tiles, i.e. a full chip of four-player games or of the direct observation: S = 3,
+    // 342 workgroups in one and a third rounds, 25.5 against 30.0 and 17.5 against 23.6 in line.)
+    h->prefer_merged = S == natural_s;
     if (const char *e = getenv("SKYJO_MERGED")) h->prefer_merged = atoi(e) != 0;
     h->merged = h->merged_capable && h->prefer_merged && !getenv("SKYJO_OVERLAP");
     if (h->merged) h->overlap = false;  // (no second stream in this form)
@@ -911,7 +920,7 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
     // The one-kernel form keeps its tiles in LDS over several dealing cycles when the caller asks for that many iterations at once:
     // up to kMaxCyclesPerLaunch whole cycles in ONE launch (the cycle ends inside it are handled by the kernel: step_body, k_cycle)
     int cycles = 1;
-    if (h->merged && run_due && h->pending_iters == 0 && h->P.L.indirect && !getenv("SKYJO_NO_MULTI_CYCLE")) {
+    if (h->merged && run_due && h->pending_iters == 0 && !getenv("SKYJO_NO_MULTI_CYCLE")) {
       cycles = (iters - done) / h->deal_every_iters;
       cycles = cycles < 1 ? 1 : (cycles > kMaxCyclesPerLaunch ? kMaxCyclesPerLaunch : cycles);
       n = cycles * h->deal_every_iters;
