@@ -1420,7 +1420,7 @@ int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
       // 0: in line; 1: beside the step kernel, in the form this engine prefers; 2: the two-stream form; 3: the one-kernel form (k_cycle)
       if (value < 0 || value > 3) return fail(SKYJO_E_INVALID, "SKYJO_OPT_OVERLAP takes 0 .. 3");
       if (value == 3 && !h->merged_capable)
-        return fail(SKYJO_E_INVALID, "the one-kernel form needs two to four players, the indirect observation and its workgroup's LDS regions within 160 KB");
+        return fail(SKYJO_E_INVALID, "the one-kernel form needs two to four players");
       h->merged = value == 3 || (value == 1 && h->merged_capable && h->prefer_merged);
       h->overlap = value != 0 && !h->merged;
       h->interval_default = deal_interval_default(h->P.L.N, h->overlap, h->piped, h->merged ? h->cycle_s : 0);

@@ -325,7 +325,7 @@ class SkyjoVecEnv:
     def set_overlap(self, on):
         """Dealing beside the step kernel (results do not depend on it).  False / 0: in line; True / 1: beside, in the form the
         engine prefers; 2: the two-stream form (k_deal on a stream of its own); 3: the one-kernel form (k_cycle: step and dealing
-        wavefronts share every CU; two or three players, indirect observation)."""
+        wavefronts share every CU; two to four players)."""
         _lib.check(self._L.skyjo_vec_set_option(self._h, 2, int(on)))
 
     def dealing_form(self):
