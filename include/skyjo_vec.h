@@ -255,7 +255,7 @@ int skyjo_vec_debug_trace(skyjo_vec *h, uint64_t *out_host);
  *      no L2 write-back / invalidation.  Two to four players, either observation; S = 1 .. 4 step and as many dealing wavefronts
  *      per workgroup, whichever spreads the batch over the CUs and fits their LDS regions into 160 KB.  A launch may span up to
  *      16 dealing cycles.  The default wherever it exists, except where the LDS forces S below the batch's share of tiles per CU
- *      (a full chip of four-player games or of the direct observation: form 0 there); the fused rollout only - other calls deal
+ *      (a full chip of four-player games: form 0 there); the fused rollout only - other calls deal
  *      as in form 0;
  *   1  "beside the step kernel" in whichever of the two forms the engine prefers.
  * skyjo_vec_get_option returns 0, 2 or 3.  Environment overrides: SKYJO_OVERLAP (0 / 1), SKYJO_MERGED (0 / 1: prefer form 3). */

@@ -109,6 +109,8 @@ struct skyjo_vec {
   uint32_t cycle_deal_tag = 0;
   size_t lds_cycle = 0;
   int cycle_s = SK_CYCLE_MAX_S;  // step (= dealing) wavefronts per workgroup of k_cycle
+  size_t lds_cycle_step = 0;     // one step wavefront's LDS region in k_cycle (lds_rollout, or lds_step when the deferred scoring has no room)
+  bool cycle_no_defer = false;
   bool inflight_piped = false; // the run(s) in flight were planned that way
   int list_sel = 0;
   uint32_t deal_tag = 0;  // k_step launches between two k_deal launches inside skyjo_vec_rollout
@@ -376,12 +378,13 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
     // one kernel for the whole dealing cycle: S step + S dealing wavefronts per workgroup (= per CU)
     uint32_t lds_deal = SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE), tag = h->cycle_deal_tag;
     h->cycle_deal_tag = 0;
+    if (h->cycle_no_defer) lds_deal |= 1u << 29;
     if (const char *e = getenv("SKYJO_CYCLE_SPLIT")) lds_deal |= (uint32_t)(atoi(e) & 3) << 30;  // diagnostic: 1 = roles by SIMD parity, 2 = by SIMD pair
     const int S = h->cycle_s;
     dim3 cgrid((h->P.tiles + S - 1) / S), cblock(2 * S * SK_TILE);
 #define LAUNCHC(I, NP)                                                                                                                 \
   hipExtLaunchKernelGGL((k_cycle<I, NP>), cgrid, cblock, (uint32_t)h->lds_cycle, s, e0, e1, 0, h->P, rec, act_out, iters, policy_seed, \
-                        h->iter, tag, (uint32_t)h->lds_rollout, lds_deal, cycle_len)
+                        h->iter, tag, (uint32_t)h->lds_cycle_step, lds_deal, cycle_len)
     switch (h->P.L.N * 2 + (ind ? 1 : 0)) {
       case 5: LAUNCHC(true, 2); break;
       case 7: LAUNCHC(true, 3); break;
@@ -601,9 +604,19 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     int S = (P.tiles + ncu - 1) / ncu;
     S = S < 1 ? 1 : (S > SK_CYCLE_MAX_S ? SK_CYCLE_MAX_S : S);
     if (const char *e = getenv("SKYJO_CYCLE_S")) S = atoi(e) >= 1 && atoi(e) <= SK_CYCLE_MAX_S ? atoi(e) : S;
-    const size_t per_s = h->lds_rollout + (size_t)SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE);
+    const size_t deal_region = (size_t)SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE);
+    size_t per_s = h->lds_rollout + deal_region;
     const int natural_s = S;
-    while (S > 1 && (size_t)S * per_s + 32 > 160 * 1024) S--;  // (the wider records of the direct observation, four players: fewer wavefronts per workgroup, more workgroups)
+    h->lds_cycle_step = h->lds_rollout, h->cycle_no_defer = false;
+    if ((size_t)S * per_s + 32 > 160 * 1024 && (size_t)S * (h->lds_step + deal_region) + 32 <= 160 * 1024 && cfg->num_players <= 3 &&
+        !getenv("SKYJO_CYCLE_DEFER_ONLY")) {
+      // the direct observation of three players on a full chip: the CU's share of tiles fits without the card chunks of the deferred
+      // scoring (the games are then scored in the iteration they end: a slower step, but one round of workgroups - 31.0 against 23.5
+      // x 10^9 in line; four players, where scoring on the spot costs more: 22.5 against 30.1 - they stay in line)
+      per_s = h->lds_step + deal_region;
+      h->lds_cycle_step = h->lds_step, h->cycle_no_defer = true;
+    }
+    while (S > 1 && (size_t)S * per_s + 32 > 160 * 1024) S--;  // (fewer wavefronts per workgroup, more workgroups)
     const size_t need = (size_t)S * per_s + 32;
     const bool fits = fixed_n && need <= 160 * 1024 && !getenv("SKYJO_LDS_PAD");
     h->lds_cycle = need, h->cycle_s = S;

@@ -1241,7 +1241,8 @@ __device__ __forceinline__ uint32_t sk_next_tag(uint32_t t) {
 template <bool INDIRECT, bool POLICY, int NP>
 __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, const int lane, uint32_t *lds_raw, const int32_t *actions,
                                           uint8_t *rec_out, int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0,
-                                          double *end_rew_out, uint8_t *end_out, uint8_t *raw_out, int raw_stride, const int cycle_len = 0) {
+                                          double *end_rew_out, uint8_t *end_out, uint8_t *raw_out, int raw_stride, const int cycle_len = 0,
+                                          const bool defer_ok = true) {
   SkParams P = Pin;
   TRACE_DECL;
   if (NP > 0) P.L = sk_make_layout(NP, INDIRECT ? 1 : 0);  // same values as the host computed, now constants
@@ -1266,7 +1267,9 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
 #pragma unroll
   for (int k = 0; k < NACC; k++) racc_store[k] = 0.0;
   double *racc = REGACC ? racc_store : nullptr;
-  uint8_t *pendp = DEFER ? stg + (INDIRECT ? 4096 : SK_TILE * (P.L.rec_bytes + 16)) + (REGACC ? 0 : SK_ACC_KINDS * P.L.N * 512) + lane * 16 : nullptr;
+  // (defer_ok false - k_cycle where four step regions WITH the card chunks of the deferred scoring would overflow a CU's LDS, four
+  // players / the direct observation on a full chip: games are scored in the iteration they end, the region is tile + staging)
+  uint8_t *pendp = DEFER && defer_ok ? stg + (INDIRECT ? 4096 : SK_TILE * (P.L.rec_bytes + 16)) + (REGACC ? 0 : SK_ACC_KINDS * P.L.N * 512) + lane * 16 : nullptr;
   int pend_fin = -1;
   if (!REGACC)
     for (int k = 0; k < SK_ACC_KINDS * P.L.N; k++) ACC(k) = 0.0;
@@ -2467,7 +2470,8 @@ __global__ __launch_bounds__(2 * SK_CYCLE_MAX_S *SK_TILE) void k_cycle(SkParams 
   extern __shared__ uint32_t lds_raw[];
   const uint32_t S = blockDim.x >> 7;  // step (= dealing) wavefronts per workgroup
   const uint32_t split = lds_deal_bytes >> 30;  // (diagnostic role splits, see below)
-  lds_deal_bytes &= 0x3fffffffu;
+  const bool defer_ok = ((lds_deal_bytes >> 29) & 1u) == 0;  // (bit 29: the step regions have no room for deferred scoring)
+  lds_deal_bytes &= 0x1fffffffu;
   uint32_t *claim = lds_raw + (((size_t)S * (lds_step_bytes + lds_deal_bytes)) >> 2);  // six words behind the 2 S regions
   const int lane = (int)(threadIdx.x & 63u);
   if (threadIdx.x < 6) claim[threadIdx.x] = 0;
@@ -2492,7 +2496,7 @@ __global__ __launch_bounds__(2 * SK_CYCLE_MAX_S *SK_TILE) void k_cycle(SkParams 
   Pin.wg_local = 1u;  // the games of tile `unit` are dealt by dealing slot `slot` of THIS workgroup: hand-overs stay inside the CU
   if (role == 0) {
     step_body<INDIRECT, true, NP>(Pin, unit, lane, lds_raw + (size_t)slot * (lds_step_bytes >> 2), nullptr, rec_out, act_out, iters, policy_seed, iter0,
-                                  nullptr, nullptr, nullptr, 0, cycle_len);
+                                  nullptr, nullptr, nullptr, 0, cycle_len, defer_ok);
 #ifdef SK_EXP_CYCLE_SYNTH  // diagnostic: the second wavefront of every SIMD runs a synthetic stream of vector instructions instead
   } else {
     uint32_t x = (uint32_t)lane * 2654435761u + (uint32_t)unit, y = x ^ 0x9e3779b9u;
