@@ -2496,7 +2496,7 @@ __global__ __launch_bounds__(2 * SK_CYCLE_MAX_S *SK_TILE) void k_cycle(SkParams 
   Pin.wg_local = 1u;  // the games of tile `unit` are dealt by dealing slot `slot` of THIS workgroup: hand-overs stay inside the CU
   if (role == 0) {
     step_body<INDIRECT, true, NP>(Pin, unit, lane, lds_raw + (size_t)slot * (lds_step_bytes >> 2), nullptr, rec_out, act_out, iters, policy_seed, iter0,
-                                  nullptr, nullptr, nullptr, 0, cycle_len, defer_ok);
+                                  nullptr, nullptr, nullptr, 0, cycle_len, NP >= 4 ? true : defer_ok);  // (four players: never without - the host does not ask for it)
 #ifdef SK_EXP_CYCLE_SYNTH  // diagnostic: the second wavefront of every SIMD runs a synthetic stream of vector instructions instead
   } else {
     uint32_t x = (uint32_t)lane * 2654435761u + (uint32_t)unit, y = x ^ 0x9e3779b9u;
