@@ -253,7 +253,9 @@ struct Stamps {
 // tag} per wavefront in P.stamps, two launches deep (slot = tag & 1): k_step rows [slot][tile], k_deal rows [2 + slot][tile]
 // (tools/dev/placement.py reads them through skyjo_vec_debug_trace).  The shipped build has none of it.
 #ifdef SK_TRACE
-#define TRACE_DECL const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime(), trace_c0 = __builtin_amdgcn_s_memtime()
+#define TRACE_DECL const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime(), trace_c0 = __builtin_amdgcn_s_memtime(); unsigned long long trace_wait = 0, trace_w0 = 0
+#define TRACE_WAIT_BEGIN trace_w0 = __builtin_amdgcn_s_memtime()
+#define TRACE_WAIT_END trace_wait += __builtin_amdgcn_s_memtime() - trace_w0
 #define TRACE_STORE(kind, tag, lane_, block_)                                                                    \
   do {                                                                                                           \
     if ((lane_) == 0) {                                                                                          \
@@ -262,10 +264,13 @@ struct Stamps {
       tr[1] = __builtin_amdgcn_s_getreg(63508); /* HW_REG_XCC_ID */                                              \
       tr[2] = trace_t0, tr[3] = __builtin_amdgcn_s_memrealtime(), tr[4] = (tag);                                 \
       tr[5] = __builtin_amdgcn_s_memtime() - trace_c0; /* shader cycles: / (end - start) x 100 MHz = the clock */ \
+      tr[6] = trace_wait; /* cycles spent at the cycle-end barriers of a k_cycle launch */                       \
     }                                                                                                            \
   } while (0)
 #else
 #define TRACE_DECL
+#define TRACE_WAIT_BEGIN
+#define TRACE_WAIT_END
 #define TRACE_STORE(kind, tag, lane_, block_)
 #endif
 
@@ -1475,7 +1480,9 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
       sk_publish_deals(P, g);
       sk_plan_deals(P, g, lane);
       P.plan_new_tag = sk_next_tag(P.plan_new_tag);
+      TRACE_WAIT_BEGIN;
       __syncthreads();  // k_cycle: the dealing wavefronts of this workgroup take the run just planned from here
+      TRACE_WAIT_END;
     }
   }
   HDR_FLUSH(h);
@@ -2532,7 +2539,13 @@ __global__ __launch_bounds__(2 * SK_CYCLE_MAX_S *SK_TILE) void k_cycle(SkParams 
         deal_body<NP>(P, 0, 3, unit, lane, lds_raw + (((size_t)S * lds_step_bytes + (size_t)slot * lds_deal_bytes) >> 2));
       }
       if (c + 1 < cycles) {
+#ifdef SK_TRACE
+        const unsigned long long dw0 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();  // (the step wavefronts arrive when they have planned the next run)
+#ifdef SK_TRACE
+        if (lane == 0) P.stamps[((size_t)2 * P.tiles + unit) * 8 + 7] += __builtin_amdgcn_s_memtime() - dw0, P.stamps[((size_t)3 * P.tiles + unit) * 8 + 7] = 0;
+#endif
         tag = planned, planned = sk_next_tag(planned);
       }
     }

@@ -25,6 +25,8 @@ def decode(rows):
     hw, xcc = rows[:, 0].astype(np.int64), rows[:, 1].astype(np.int64) & 0xf
     simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 0xf, (hw >> 12) & 1, (hw >> 13) & 7
     cu_key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    global WAITS
+    WAITS = rows[:, 6].astype(np.int64)
     return cu_key, cu_key * 4 + simd, rows[:, 2].astype(np.int64), rows[:, 3].astype(np.int64), int(rows[0, 4]), rows[:, 5].astype(np.int64)
 
 
@@ -36,6 +38,9 @@ for kind, name in ((0, "k_step"), (1, "k_deal")):
         if not rows[:, 3].any():
             continue
         launches[(name, slot)] = decode(rows)
+        out.setdefault("barrier_wait_cycles_mean", {})[f"{name}[{slot}]"] = float(WAITS.mean())
+        if kind == 1:
+            out.setdefault("deal_barrier_wait_cycles_total_mean (all launches so far)", {})[f"{name}[{slot}]"] = float(rows[:, 7].astype(np.int64).mean())
 t_ref = min(v[2].min() for v in launches.values())
 for (name, slot), (cu, simd, t0, t1, tag, cyc) in sorted(launches.items()):
     d = (t1 - t0) / 100.0  # us
