@@ -411,3 +411,35 @@ def test_dealing_interval_adapts_to_short_episodes():
     assert eng.deal_interval() < 56
     assert early > 0 and late <= early / 2
     eng.close()
+
+
+@pytest.mark.parametrize("form", [0, 3])
+def test_rollout_without_auto_reset_runs_every_game_to_its_end(form):
+    """auto_reset off under the fused rollout (in line and in the one-kernel form, several dealing cycles per launch): every game
+    plays its first episode to the end and then stands still (status NOOP_DONE, its last record repeated), whatever the dealing
+    wavefronts do beside it; every record equals the oracle's."""
+    import torch
+
+    B, N, K = 5000, 3, 256
+    cfg = dict(num_players=N, score_penalty=2.0, observe_other_player_indirect=True, mean_reward=1.0, reward_refunded=0.001, rng_mode=0,
+               auto_reset=False)
+    eng = _engine(B, **cfg)
+    eng.set_overlap(form)
+    ora = _oracle_vec(num_envs=B, **cfg)
+    eng.seed(None, 3)
+    ora.seed(None, 3)
+    rec = eng.new_records(K)
+    eng.rollout(K, policy_seed=11, records=rec)
+    oact, obs, mask, meta, eplen = ora.rollout(K, 11, threads=8, record_obs=True)
+    v = eng.split(rec)
+    np.testing.assert_array_equal(v.action.cpu().numpy(), oact.astype(np.int8))
+    np.testing.assert_array_equal(v.observations.cpu().numpy(), obs)
+    np.testing.assert_array_equal(v.action_mask.cpu().numpy(), mask)
+    np.testing.assert_array_equal(v.done.cpu().numpy(), meta[..., 2])
+    np.testing.assert_array_equal(v.status.cpu().numpy(), meta[..., 3])
+    c = eng.counters()
+    assert c["episodes"] == B and c["resets"] == 0 and bool((v.status[K - 1] == 2).all())  # SKYJO_ST_NOOP_DONE everywhere at the end
+    rew, sc, done = eng.rewards_host()
+    assert done.all()
+    np.testing.assert_array_equal(rew, ora.rewards)
+    eng.close()
