@@ -318,7 +318,7 @@ def test_mixed_calls_while_dealing_runs_are_in_flight(seed, N, B):
             eng.rollout(int(rng.integers(1, 60)), policy_seed=999)
             eng.restore(snap)
         elif op == "overlap":
-            eng.set_overlap(bool(rng.integers(0, 2)))
+            eng.set_overlap(int(rng.choice([0, 1, 2, 3])))  # in line / the engine's choice / two streams / one kernel (k_cycle)
         else:
             eng.set_deal_interval(int(rng.integers(4, 100)))
         same(f"round {r} after {op}")
