@@ -206,8 +206,11 @@ def side_rollout_config(name, B, N, steps, warmup, device, rng_mode, indirect=Tr
     out = {"workload": f"{B} x {N}-player games, {'indirect' if indirect else 'direct'} observation D={eng.obs_dim}, "
                        f"{'mt19937' if rng_mode == 0 else 'philox'} deals" + (f", game_id0={game_id0}" if game_id0 else ""),
            "value": c["steps"] / dt, "unit": "env-steps/s", "ms_per_iteration": 1e3 * dt / (steps * chunk),
-           "iterations_per_launch": chunk, "timed_launches": steps, "dominant_kernel": "k_step",
-           "dominant_kernel_ms": k_ms, "deal_kernel_ms": prof["deal_ms"] / max(prof["deal_launches"], 1),
+           "iterations_per_launch": chunk, "timed_launches": steps,
+           "dominant_kernel": (f"k_cycle<{'indirect' if indirect else 'direct'},{N}> ({mult} dealing cycles per launch, the dealing runs inside)"
+                               if eng.dealing_form() == "one kernel" else "k_step"),
+           "dominant_kernel_ms": k_ms,
+           "deal_kernel_ms": None if eng.dealing_form() == "one kernel" else prof["deal_ms"] / max(prof["deal_launches"], 1),
            "roofline_frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
            "dealing": eng.dealing_form(), "waits": int(c["waits"]),
            "mean_episode_len": c["sum_len"] / max(c["episodes"], 1)}
@@ -421,7 +424,7 @@ def main():
     traffic, deal_traffic, traffic_source = committed_traffic(shape)
     path_traffic = traffic if (traffic is not None and eng.dealing_form() == "one kernel") else (
         traffic + deal_traffic if traffic is not None and deal_traffic is not None else None)  # (k_cycle's counters already hold both roles)
-    kernel_ms = {k: prof[k + "_ms"] / 32.0 for k in ("k_step", "k_scan", "k_deal", "k_publish")}  # per bench step (= per dealing cycle)
+    kernel_ms = {k: prof[k + "_ms"] / 32.0 for k in ("k_step", "k_scan", "k_deal", "k_publish")}  # per bench step = per LAUNCH (k_cycle: CYCLES_PER_LAUNCH dealing cycles, slot "k_step")
     path_ms = sum(kernel_ms.values())
     wall_ms = 1e3 * t_max / args.steps
     # the dealing kernel's own algorithmic traffic (MT19937 mode): per RNG output one state word read as the old element, one

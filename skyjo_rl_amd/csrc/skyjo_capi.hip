@@ -933,7 +933,9 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
     // The one-kernel form keeps its tiles in LDS over several dealing cycles when the caller asks for that many iterations at once:
     // up to kMaxCyclesPerLaunch whole cycles in ONE launch (the cycle ends inside it are handled by the kernel: step_body, k_cycle)
     int cycles = 1;
-    if (h->merged && run_due && h->pending_iters == 0 && !getenv("SKYJO_NO_MULTI_CYCLE")) {
+    // (only where the kernel's cycle ends have a run to hand over: an engine that never deals ahead - SKYJO_OPT_NO_BANK - plans nothing,
+    // and a cycle end inside its launch would publish and plan with a stale id: ADVICE r4)
+    if (h->merged && piped && run_due && h->pending_iters == 0 && !getenv("SKYJO_NO_MULTI_CYCLE")) {
       cycles = (iters - done) / h->deal_every_iters;
       cycles = cycles < 1 ? 1 : (cycles > kMaxCyclesPerLaunch ? kMaxCyclesPerLaunch : cycles);
       n = cycles * h->deal_every_iters;

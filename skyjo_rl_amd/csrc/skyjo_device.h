@@ -14,10 +14,10 @@
 // cycle whose workgroups hold step AND dealing wavefronts of the same games, so that a dealt episode changes hands inside a CU
 // (workgroup-scope release / acquire instead of an L2 write-back / invalidation per wavefront: see k_cycle).
 //
-// Diagnostic builds (tools/dev/): -DSK_STAMPS (section cycle counters), -DSK_TRACE (placement, time span and clock of every
-// wavefront), -DSK_EXP_NO_SCORE / _NO_RARE / _NO_FENCE / _REC_WRAP / _DEAL_NO_LOADS / _DEAL_NO_STORES / _DEAL_NO_PARTNERS /
-// _DEAL_NO_DECK / _DEAL_NO_TEMPER / _CYCLE_SYNTH (leave a piece out or put a synthetic one in and time the rest; results are then
-// wrong on purpose - EXPERIMENTS.md says what each of them showed).
+// Diagnostic builds (tools/dev/): -DSK_STAMPS / -DSK_STAMPS_FINE (section cycle counters), -DSK_TRACE (placement, time span and
+// clock of every wavefront).  Neither changes a result.  The round-4 timing switches that left pieces out on purpose (wrong
+// results) are no longer part of this file: tools/dev/sk_exp_switches.patch puts them back for whoever wants to repeat the
+// experiments of EXPERIMENTS.md round 4.
 //
 // Semantics follow rlskyjo/game/skyjo.py and rlskyjo/environment/skyjo_env.py; each function
 // cites the lines it restates.  Nothing here shares code with oracle/.
@@ -107,10 +107,6 @@ struct LaneCounters {
 // chip (EXPERIMENTS.md round 4: 25.7 -> 34.0 x 10^9 steps/s without them).  Inside k_cycle both are wavefronts of ONE workgroup,
 // i.e. of one CU - they share its vector L1 (write-through) and its XCD's L2: workgroup scope is all the memory model asks for,
 // and on gfx950 that is a wait for the wavefront's own stores and nothing else (P.wg_local).
-#ifdef SK_EXP_NO_FENCE  // timing build: no cache maintenance around the hand-over at all (results may be stale)
-#define SK_FENCE_ACQUIRE(P) asm volatile("" ::: "memory")
-#define SK_FENCE_RELEASE(P) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#else
 #define SK_FENCE_ACQUIRE(P)                                              \
   do {                                                                   \
     if ((P).wg_local) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
@@ -121,7 +117,6 @@ struct LaneCounters {
     if ((P).wg_local) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
     else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");              \
   } while (0)
-#endif
 #define SK_RARE(x) __builtin_expect(!!(x), 0)
 #define SK_OFTEN(x) __builtin_expect(!!(x), 1)
 #define LIDX(b) ((((b) >> 4) << 10) | ((b) & 15))
@@ -867,11 +862,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
     const int role = (h.w1 >> 16) & 1;
     int nd = h.w1 & 0xff;
     const int ns = (h.w1 >> 8) & 0xff;
-#ifndef SK_NO_ROW_PRE
     const int hidden_p = (int)((row_pre.w >> 16) & 0xffu);
-#else
-    const int hidden_p = LB(blk + PB_HIDDEN);
-#endif
     int pile_top = LI(pb + pile_addr(role, nd > 0 ? nd - 1 : 0));
     const int disc_top = LI(pb + pile_addr(role ^ 1, ns > 0 ? ns - 1 : 0));
     const int disc_below = LI(pb + pile_addr(role ^ 1, ns > 1 ? ns - 2 : 0));
@@ -879,7 +870,6 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
     if (hidden_p == 0) {
       h.w0 |= (uint32_t)(F_TERMINATED | F_DONE) << 16;
       LB(H_FINISHER) = (uint8_t)p;
-#ifndef SK_EXP_NO_SCORE
       if (NP > 0 && NP < 8) {
         constexpr int NQ = (NP > 0 && NP < 8) ? NP : 1;
         P.done[g] = 1;
@@ -893,9 +883,6 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
       } else {
         finish_game(P, lp, fp, ap, g, p);
       }
-#else
-      P.done[g] = 1;
-#endif
       cnt.episodes++;
       cnt.sum_len += eplen;
 #ifdef SK_STAMPS_FINE
@@ -906,9 +893,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
     const bool from_pile = a == 24;
     if (from_pile && nd == 0) {  // rare: works on the LDS copy of the header
       HDR_FLUSH(h);
-#ifndef SK_EXP_NO_RARE
       reshuffle_dispatch(P, lp, fp, g);
-#endif
       HDR_LOAD(h);
       cnt.reshuffles++;
       nd = h.w1 & 0xff;
@@ -936,11 +921,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
   const int hand = (int)(int8_t)(h.w2 >> 24);
   const int reg = ((h.w1 >> 16) & 1) ^ 1;
   int ns = (h.w1 >> 8) & 0xff;
-#ifndef SK_NO_ROW_PRE
   const uint4 row = row_pre;  // the acting player's cards and his counters: requested before the policy picked
-#else
-  const uint4 row = LQ(blk >> 4);  // the acting player's cards and his counters: one read
-#endif
   const uint32_t c0 = row.x, c1 = row.y, c2 = row.z;
   int sum = (int)(int16_t)(row.w & 0xffffu), hid = (int)((row.w >> 16) & 0xffu), refunded = (int)(row.w >> 24);
   // minima over the OTHER players do not change in this turn (skyjo.py:182-183)
@@ -1176,7 +1157,7 @@ __device__ __forceinline__ void sk_publish_deals(const SkParams &P, int g) {
     }
   }
 }
-__device__ __forceinline__ void sk_plan_deals(const SkParams &P, int g, int lane) {
+__device__ __forceinline__ void sk_plan_deals(const SkParams &P, int g, int lane, const bool report = true) {
   const size_t G = (size_t)P.tiles * SK_TILE;
   bool need = false, empty = false;
   if (g < P.B) {
@@ -1205,7 +1186,11 @@ __device__ __forceinline__ void sk_plan_deals(const SkParams &P, int g, int lane
       P.plan_tag[g] = P.plan_new_tag;
     }
   }
-  const unsigned long long be = __ballot(empty);
+  // `report` false - the cycle ends INSIDE a k_cycle launch: the dealing wavefront that hands the count to the host (deal_body,
+  // piped form) reads and clears the word of its run's parity while other workgroups of the same launch may be planning that
+  // very run or one two cycles on - counts would be lost or land on the wrong run.  So only the plan on the way OUT of a launch
+  // counts (complete when the next launch's dealing wavefronts look at it): adapt_interval sees one run per launch.
+  const unsigned long long be = __ballot(empty && report);
   if (be && lane == 0) atomicAdd(P.bank_empty + (P.plan_new_tag & 1u), (uint32_t)__popcll(be));  // (rare)
 }
 
@@ -1279,9 +1264,6 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
   if (!REGACC)
     for (int k = 0; k < SK_ACC_KINDS * P.L.N; k++) ACC(k) = 0.0;
   STAMP_DECL;
-#ifdef SK_STEP_PRIO
-  __builtin_amdgcn_s_setprio(SK_STEP_PRIO);  // ahead of a dealing wavefront that shares the SIMD
-#endif
   // the tile comes in by LDS-DMA as well (non-temporal: it is read once per launch)
   dma_record<true>((const uint8_t *)P.state, (uint32_t)((((size_t)tile * P.L.chunks) * SK_TILE + lane) * 16), lds_tile, P.L.chunks);
   if (P.ov_flags & 1u) sk_publish_deals(P, g);  // (while the tile is on its way)
@@ -1321,13 +1303,9 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
       if (!over && !skip) {
         const uint32_t v0 = ob.q0, v1 = ob.q1, v2 = ob.q2;  // the acting player's row, read for the previous record
         STAMP(2);
-#ifndef SK_NO_ROW_PRE
         // the acting player's card chunk (cards, sum, hidden, refunded) is on its way while the policy picks
         const uint4 row_pre = LQ(sk_pb(P.L, (h.w0 >> 8) & 0xff) >> 4);
         asm volatile("" ::: "memory");  // (the request stays up here: the compiler would sink it to its first use)
-#else
-        const uint4 row_pre = make_uint4(0u, 0u, 0u, 0u);
-#endif
         if (POLICY) a = policy_pick(h.w0 & 0xff, ob, word);
 #ifndef SK_STAMPS_FINE
         STAMP(3);
@@ -1343,9 +1321,7 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
         if (P.auto_reset) {
           bool dealt = true;
           if (!spare_commit(P, lp, g, sp)) {
-#ifndef SK_EXP_NO_RARE
             dealt = deal_inline(P, lp, fp, g, tile, lane, sp.head);
-#endif
             cnt.waits++;  // counts the slow-path deals
           }
           HDR_LOAD(h);
@@ -1450,11 +1426,7 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
       // in it (k_step -7 %, k_deal -12 % together).  Staging slot of (record r, piece p): r * 64 + ((p + (r >> 1)) & 3)
       // * 16 - both the lane-per-record writes above and the lane-per-16-bytes reads here are bank-conflict free.
       typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-#ifdef SK_EXP_REC_WRAP
-      uint8_t *blk = rec_out + ((size_t)(it & 1) * P.B + (size_t)tile * SK_TILE) * 64;
-#else
       uint8_t *blk = rec_out + ((size_t)it * P.B + (size_t)tile * SK_TILE) * 64;
-#endif
       const int live = P.B - tile * SK_TILE;  // records of this tile that exist (the last tile may be partial)
       // all four pieces are requested before the first is used: ONE LDS round trip (guarded one by one, each read sat
       // behind its own wait inside its own exec-masked block: four round trips and eight branches per iteration)
@@ -1478,7 +1450,7 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
     if (POLICY && cycle_len && it + 1 < iters && (it + 1) % cycle_len == 0) {  // (wavefront-uniform) a dealing cycle ends inside the launch
       if (P.busy[g]) (void)wait_deal_done(P, g);
       sk_publish_deals(P, g);
-      sk_plan_deals(P, g, lane);
+      sk_plan_deals(P, g, lane, false);
       P.plan_new_tag = sk_next_tag(P.plan_new_tag);
       TRACE_WAIT_BEGIN;
       __syncthreads();  // k_cycle: the dealing wavefronts of this workgroup take the run just planned from here
@@ -1756,14 +1728,6 @@ struct MtChunkStream {
   __device__ __forceinline__ int close() const { return wrap(base + pos) | (((16 - pos) & 31) << 16); }
   __device__ __forceinline__ void issue() {
     const int c = gen;
-#ifdef SK_EXP_DEAL_NO_LOADS  // timing build (results wrong on purpose): no generator-state loads at all
-#pragma unroll
-    for (int k = 0; k < 17; k++) o[k] = (my_off + (uint32_t)c + (uint32_t)k) * 2654435761u;
-#pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = o[k] ^ (o[k + 1] >> 7);
-    xw = x[3];
-    return;
-#endif
     const uint4 *po = (const uint4 *)(mt + c);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1771,12 +1735,6 @@ struct MtChunkStream {
       o[4 * k] = q.x, o[4 * k + 1] = q.y, o[4 * k + 2] = q.z, o[4 * k + 3] = q.w;
     }
     o[16] = mt[c + 16 == 624 ? 0 : c + 16];
-#ifdef SK_EXP_DEAL_NO_PARTNERS  // timing build: the chunk itself is loaded, its partners are not
-#pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = o[k] ^ (o[k + 1] >> 7);
-    xw = x[3];
-    return;
-#endif
     // The partners i + 397 (mod 624), without a branch (with the two cases in two exec-masked blocks the compiler merges their
     // registers behind each block and waits for the loads right there, a few instructions after they were issued).  Chunk 224 is the one whose partners wrap (621, 622, 623,
     // 0 .. 12): its pieces 1 .. 3 are words 1 .. 12 = (224 - 227) + 4 k like every chunk above it, piece 0 is read at 621
@@ -1816,17 +1774,8 @@ struct MtChunkStream {
     base = live ? c : base, pos = live ? 0 : pos, chunks_made += live ? 1 : 0;
     gen = live ? (c + 16 == 624 ? 0 : c + 16) : c;
     const uint32_t lm = live ? 0xffffffffu : 0u;  // (a select the compiler cannot turn into a branch around the tempering)
-#ifdef SK_EXP_DEAL_NO_TEMPER  // timing build: six vector instructions fewer per output
-#pragma unroll
-    for (int k = 0; k < 16; k++) R[k] = __builtin_amdgcn_bitop3_b32(R[k], v[k], lm, 0xd8);
-#else
 #pragma unroll
     for (int k = 0; k < 16; k++) R[k] = __builtin_amdgcn_bitop3_b32(R[k], mt_temper3(v[k]), lm, 0xd8);
-#endif
-#ifdef SK_EXP_DEAL_NO_STORES  // timing build: the regenerated chunk is not written back
-    issue();
-    return;
-#endif
     uint8_t *row = stg + lane * SK_STG_STRIDE;
 #pragma unroll
     for (int k = 0; k < 4; k++) ((uint4 *)row)[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
@@ -1904,13 +1853,6 @@ __device__ __forceinline__ void deck_batch(Rng &r, const int s, uint32_t *lds_ra
   }
   w.nxt_n = w.pb == dk ? R : 0u;  // (a batch never holds two completions: the rest takes > 100 draws)
   uint32_t cI[BS], cJ[BS];
-#ifdef SK_EXP_DEAL_NO_DECK  // timing build: the walk's arithmetic without its LDS accesses
-#pragma unroll
-  for (int k = 0; k < BS; k++) cI[k] = pI[k] & 15u, cJ[k] = pJ[k] & 15u;
-  asm volatile("" : "+v"(cI[0]), "+v"(cJ[0]), "+v"(cI[BS - 1]), "+v"(cJ[BS - 1]));
-  w.nxt_n ^= (cI[0] ^ cJ[BS - 1]) >> 20;  // (keeps the values alive; always zero)
-  return;
-#endif
 #pragma unroll
   for (int k = 0; k < BS; k++) cI[k] = DK_AT(pI[k]), cJ[k] = DK_AT(pJ[k]);
   // What step k finds at its two positions is what the batch's earlier steps left there.  Only an earlier step's
@@ -2295,7 +2237,8 @@ __global__ __launch_bounds__(256) void k_publish_all(SkParams P) {
 
 // One dealing wavefront: games block * 64 .. (lane = game in the forms without a work list), its own LDS region `lds_raw`.
 template <int NP>
-__device__ __forceinline__ void deal_body(const SkParams &P, int list_sel, int publish_inline, const int block, const int lane, uint32_t *lds_raw) {
+__device__ __forceinline__ void deal_body(const SkParams &P, int list_sel, int publish_inline, const int block, const int lane, uint32_t *lds_raw,
+                                          const bool report_health = true) {
   TRACE_DECL;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 16;
   const size_t G = (size_t)P.tiles * SK_TILE;
@@ -2306,7 +2249,7 @@ __device__ __forceinline__ void deal_body(const SkParams &P, int list_sel, int p
   // publish_inline == 3: beside the step kernel, lane = game as well - the step kernel planned this run on its way out
   // (sk_plan_deals) and publishes it on its way into a later launch; this kernel deals and signals, as with a work list
   const bool fused = publish_inline == 2, piped = publish_inline == 3;
-  if (piped && block == 0 && lane == 0) {
+  if (piped && report_health && block == 0 && lane == 0) {
     uint32_t *be = P.bank_empty + (P.deal_tag & 1u);  // the launch that planned this run has finished: its count is complete
     P.health_host[0] = *be, P.health_host[1] = P.deal_tag;
     *be = 0;
@@ -2499,34 +2442,17 @@ __global__ __launch_bounds__(2 * SK_CYCLE_MAX_S *SK_TILE) void k_cycle(SkParams 
     slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
   }
   const int unit = (int)(blockIdx.x * S + slot);
-  if (unit >= Pin.tiles) return;
+  if (unit >= Pin.tiles) {
+    // a surplus wavefront of the last workgroup (tiles % S != 0): it has no tile, but it is a member of the workgroup - it meets the
+    // others at every cycle-end barrier of a launch of several cycles (step and dealing wavefronts both pass (iters - 1) / cycle_len
+    // of them), so that no barrier is ever executed by a part of the workgroup only
+    for (int c = cycle_len > 0 ? (iters - 1) / cycle_len : 0; c > 0; c--) __syncthreads();
+    return;
+  }
   Pin.wg_local = 1u;  // the games of tile `unit` are dealt by dealing slot `slot` of THIS workgroup: hand-overs stay inside the CU
   if (role == 0) {
     step_body<INDIRECT, true, NP>(Pin, unit, lane, lds_raw + (size_t)slot * (lds_step_bytes >> 2), nullptr, rec_out, act_out, iters, policy_seed, iter0,
                                   nullptr, nullptr, nullptr, 0, cycle_len, NP >= 4 ? true : defer_ok);  // (four players: never without - the host does not ask for it)
-#ifdef SK_EXP_CYCLE_SYNTH  // diagnostic: the second wavefront of every SIMD runs a synthetic stream of vector instructions instead
-  } else {
-    uint32_t x = (uint32_t)lane * 2654435761u + (uint32_t)unit, y = x ^ 0x9e3779b9u;
-#if SK_EXP_CYCLE_SYNTH == 1  // a loop of a few instructions (no instruction-fetch traffic to speak of)
-#pragma unroll 1
-    for (int k = 0; k < 12000; k++) {
-      x = (x ^ (y >> 3)) + 0x7f4a7c15u, y = (y ^ (x << 5)) + x;
-      x = (x ^ (y >> 7)) + 0x2545f491u, y = (y ^ (x << 9)) + x;
-      asm volatile("" : "+v"(x), "+v"(y));
-    }
-#else  // the same arithmetic as 30 000 instructions of straight-line code, run 4 times (every instruction fetched anew)
-#pragma unroll 1
-    for (int rep = 0; rep < 4; rep++) {
-#pragma unroll
-      for (int k = 0; k < 3000; k++) {
-        x = (x ^ (y >> 3)) + 0x7f4a7c15u + (uint32_t)k, y = (y ^ (x << 5)) + x;
-        x = (x ^ (y >> 7)) + 0x2545f491u, y = (y ^ (x << 9)) + x;
-        asm volatile("" : "+v"(x), "+v"(y));
-      }
-    }
-#endif
-    if (x == 0x12345678u && y == 1u) Pin.stamps[0] = x;  // (keeps the stream alive)
-#else
   } else {
     // the run the previous launch planned (deal_tag_run, 0 = none), then - a launch of several dealing cycles - the runs its step
     // wavefronts plan at the cycle ends inside it: ids plan_new_tag, + 1, ... (the last one is left to the next launch)
@@ -2536,7 +2462,7 @@ __global__ __launch_bounds__(2 * SK_CYCLE_MAX_S *SK_TILE) void k_cycle(SkParams 
     for (int c = 0; c < cycles; c++) {
       if (tag) {
         P.deal_tag = tag;
-        deal_body<NP>(P, 0, 3, unit, lane, lds_raw + (((size_t)S * lds_step_bytes + (size_t)slot * lds_deal_bytes) >> 2));
+        deal_body<NP>(P, 0, 3, unit, lane, lds_raw + (((size_t)S * lds_step_bytes + (size_t)slot * lds_deal_bytes) >> 2), c == 0);
       }
       if (c + 1 < cycles) {
 #ifdef SK_TRACE
@@ -2549,7 +2475,6 @@ __global__ __launch_bounds__(2 * SK_CYCLE_MAX_S *SK_TILE) void k_cycle(SkParams 
         tag = planned, planned = sk_next_tag(planned);
       }
     }
-#endif
   }
 }
 

@@ -55,14 +55,20 @@ def combine_stats(per_rank, num_players):
 
 
 def gather_stats(counters, num_players, device=None):
-    """All-gather the per-rank statistics record; returns (per_rank [W, F] ndarray, totals dict)."""
+    """All-gather the per-rank statistics record; returns (per_rank [W, F] ndarray, totals dict).
+
+    Whenever a process group is initialised the record goes through ``dist.all_gather`` - also with ONE rank (a single-rank RCCL
+    communicator is a real communicator: tests/test_gpu_rccl.py runs exactly that on a one-GPU box, the only place where the
+    "nccl" leg of this function can execute before an 8-GPU node is at hand).  Without a process group the record stays local."""
     import torch
     import torch.distributed as dist
 
     rec = torch.tensor(stats_record(counters, num_players), dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         if dist.get_backend() == "gloo":  # (gloo gathers host tensors only; "nccl" = RCCL takes the device tensor as it is)
             rec = rec.cpu()
+        else:
+            assert rec.is_cuda, "the RCCL all-gather takes the record where it lives: pass device=torch.device('cuda', i)"
         out = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
         dist.all_gather(out, rec)
         allr = torch.stack(out).cpu().numpy()

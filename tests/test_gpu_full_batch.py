@@ -50,15 +50,36 @@ CASES = [
     # inside it are handled by the kernel, the tiles stay in LDS) - what bench.py measures, with eight
     ("cfg3_four_cycles_per_launch", 65536, 3, True, 0, 0, 2, -4, 0),    # (K < 0: that many dealing cycles of the engine's interval)
     ("cfg2_eight_cycles_per_launch", 4096, 2, True, 0, 0, 2, -8, 0),
+    # round 5 (VERDICT r4 "weak" #1): the launch shapes bench.py TIMES, every record of them - eight dealing cycles per launch at
+    # S = 4 (the headline launch: 512 iterations), sixteen (the ABI's maximum, 1 024 iterations), the config-4 shard's eight cycles at
+    # S = 2 (bench's 640 iterations), four players at S = 3, and the cycle ends inside a launch with a PARTIAL last workgroup (tiles
+    # not a multiple of S: surplus wavefronts at the cycle-end barriers) and a partial last tile, at S = 3, 2 and (forced) 4.
+    # The oracle records in slices of 64 iterations while the engine does ONE launch (host memory stays bounded).
+    ("cfg3_eight_cycles", 65536, 3, True, 0, 0, 2, -8, 0),
+    ("cfg3_sixteen_cycles", 65536, 3, True, 0, 0, 2, -16, 0),
+    ("cfg4_shard_eight_cycles_S2", 32768, 3, True, 0, 3 * 32768, 2, -8, 0),
+    ("N4_S3_four_cycles", 49152, 4, True, 0, 0, 2, -4, 0),
+    ("partial_wg_S3_multi_cycle", 40010, 2, True, 0, 0, 3, -4, 0),     # 626 tiles = 208 workgroups of 3 + one of 2; last tile 10 games
+    ("partial_wg_S2_multi_cycle", 16400, 3, True, 0, 0, 3, -4, 0),     # 257 tiles = 128 workgroups of 2 + one of 1; last tile 16 games
+    ("surplus_wavefronts_S4_7_tiles", 440, 3, True, 0, 0, 4, -4, 0),   # SKYJO_CYCLE_S=4: one workgroup of 4 tiles + one of 3
+    ("direct_obs_eight_cycles", 65536, 3, False, 0, 0, 1, -8, 0),      # (bench's other_configs.direct_obs_65536x3 launch)
+    ("philox_eight_cycles", 65536, 3, True, 1, 0, 1, -8, 0),           # (other_configs.philox_65536x3)
 ]
+ONE_KERNEL = {"cfg3_headline", "cfg2", "cfg4_shard", "philox", "cfg5_shape_N4_one_kernel_S3", "cfg3_four_cycles_per_launch",
+              "cfg2_eight_cycles_per_launch", "cfg3_eight_cycles", "cfg3_sixteen_cycles", "cfg4_shard_eight_cycles_S2", "N4_S3_four_cycles",
+              "partial_wg_S3_multi_cycle", "partial_wg_S2_multi_cycle", "surplus_wavefronts_S4_7_tiles", "direct_obs_eight_cycles",
+              "philox_eight_cycles"}
+SLICE = 64  # iterations the oracle records at a time
 
 
 @pytest.mark.parametrize("name,B,N,ind,rng_mode,gid0,launches,K,interval", CASES, ids=[c[0] for c in CASES])
-def test_every_game_of_the_batch_against_the_oracle(name, B, N, ind, rng_mode, gid0, launches, K, interval):
+def test_every_game_of_the_batch_against_the_oracle(name, B, N, ind, rng_mode, gid0, launches, K, interval, monkeypatch):
     import torch
     from oracle import skyjo_oracle as so
     from skyjo_rl_amd import SkyjoVecEnv
 
+    if name == "surplus_wavefronts_S4_7_tiles":
+        monkeypatch.setenv("SKYJO_CYCLE_S", "4")  # (read when the engine is created)
     cfg = _cfg(N, ind, rng_mode)
     eng = SkyjoVecEnv(B, game_id0=gid0, **cfg)
     ora = so.OracleVec(num_envs=B, game_id0=gid0, **cfg)
@@ -66,32 +87,36 @@ def test_every_game_of_the_batch_against_the_oracle(name, B, N, ind, rng_mode, g
         eng.set_deal_interval(interval)
     elif interval < 0:
         eng.set_overlap({-1: 0, -2: 2}[interval])
-    if name in ("cfg3_headline", "cfg2", "cfg4_shard", "philox", "cfg5_shape_N4_one_kernel_S3", "cfg3_four_cycles_per_launch", "cfg2_eight_cycles_per_launch"):
+    if name in ONE_KERNEL:
         assert eng.dealing_form() == "one kernel", (name, eng.dealing_form())
     if K < 0:
+        eng.set_deal_interval(eng.deal_interval())  # (pinned: a launch of whole cycles is what the case is about)
         K = -K * eng.deal_interval()
     eng.seed(None, 0)
     ora.seed(None, 0)
     rec = eng.new_records(K)
     for r in range(launches):
-        eng.rollout(K, policy_seed=1, records=rec)
-        oact, obs, mask, meta, eplen = ora.rollout(K, 1, threads=THREADS, record_obs=True)
-        v = eng.split(rec)
-        # every one of the K x B records, whole
-        np.testing.assert_array_equal(v.action.cpu().numpy(), oact.astype(np.int8), err_msg=f"{name}: action bytes, launch {r}")
-        np.testing.assert_array_equal(v.observations.cpu().numpy(), obs, err_msg=f"{name}: observations, launch {r}")
-        np.testing.assert_array_equal(v.action_mask.cpu().numpy(), mask, err_msg=f"{name}: action masks, launch {r}")
-        np.testing.assert_array_equal(v.agent.cpu().numpy(), meta[..., 0], err_msg=f"{name}: agent, launch {r}")
-        np.testing.assert_array_equal(v.phase.cpu().numpy(), meta[..., 1], err_msg=f"{name}: phase, launch {r}")
-        np.testing.assert_array_equal(v.done.cpu().numpy(), meta[..., 2], err_msg=f"{name}: done, launch {r}")
-        np.testing.assert_array_equal(v.status.cpu().numpy(), meta[..., 3], err_msg=f"{name}: status, launch {r}")
-        np.testing.assert_array_equal(v.episode_steps.cpu().numpy().astype(np.uint16), eplen, err_msg=f"{name}: episode steps, launch {r}")
-        del obs, mask, meta, eplen
+        eng.rollout(K, policy_seed=1, records=rec)  # ONE call (for K = whole cycles of the one-kernel form: ONE launch)
+        for s0 in range(0, K, SLICE):
+            n = min(SLICE, K - s0)
+            oact, obs, mask, meta, eplen = ora.rollout(n, 1, threads=THREADS, record_obs=True)
+            v = eng.split(rec[s0:s0 + n])
+            at = f"{name}: launch {r}, iterations {s0}..{s0 + n - 1}"
+            # every one of the K x B records, whole
+            np.testing.assert_array_equal(v.action.cpu().numpy(), oact.astype(np.int8), err_msg=f"action bytes, {at}")
+            np.testing.assert_array_equal(v.observations.cpu().numpy(), obs, err_msg=f"observations, {at}")
+            np.testing.assert_array_equal(v.action_mask.cpu().numpy(), mask, err_msg=f"action masks, {at}")
+            np.testing.assert_array_equal(v.agent.cpu().numpy(), meta[..., 0], err_msg=f"agent, {at}")
+            np.testing.assert_array_equal(v.phase.cpu().numpy(), meta[..., 1], err_msg=f"phase, {at}")
+            np.testing.assert_array_equal(v.done.cpu().numpy(), meta[..., 2], err_msg=f"done, {at}")
+            np.testing.assert_array_equal(v.status.cpu().numpy(), meta[..., 3], err_msg=f"status, {at}")
+            np.testing.assert_array_equal(v.episode_steps.cpu().numpy().astype(np.uint16), eplen, err_msg=f"episode steps, {at}")
+            del obs, mask, meta, eplen
     c, oc = eng.counters(), ora.counters()
     for k in ("steps", "episodes", "illegal", "resets", "sum_len"):
         assert c[k] == oc[k], (name, k, c[k], oc[k])
     assert c["steps"] + c["resets"] == launches * K * B and c["illegal"] == 0
-    assert c["episodes"] > (B // 2 if launches > 3 else B // 8)
+    assert c["episodes"] > (B // 2 if launches * K > 200 else B // 8)
     if interval > 0:
         assert c["waits"] > B // 2, (name, c["waits"])  # (the case exists for the in-place deals)
     elif N <= 4:
@@ -101,6 +126,44 @@ def test_every_game_of_the_batch_against_the_oracle(name, B, N, ind, rng_mode, g
     rew, sc, done = eng.rewards_host()
     np.testing.assert_array_equal(done.astype(bool), dn)
     np.testing.assert_array_equal(rew[dn], ora.rewards[dn])
+    eng.close()
+
+
+def test_an_engine_that_never_deals_ahead_over_several_intervals_in_one_call():
+    """SKYJO_OPT_NO_BANK engines (the global-RNG single-game views) with the one-kernel form as their default -
+    a rollout call of several dealing intervals must not take the multi-cycle launch (its cycle ends publish and plan runs that such
+    an engine never has): every record of the call equals the oracle's, every reset was dealt in place, and every game's stream is
+    where numpy's would be (rng_get: key and position - the rng_get_state / rng_set_state contract)."""
+    from oracle import skyjo_oracle as so
+    from skyjo_rl_amd import SkyjoVecEnv
+
+    B, N = 320, 3
+    cfg = _cfg(N, True, 0)
+    eng = SkyjoVecEnv(B, no_bank=True, **cfg)
+    ora = so.OracleVec(num_envs=B, **cfg)
+    eng.seed(None, 5)
+    ora.seed(None, 5)
+    K = 3 * eng.deal_interval() + 7
+    rec = eng.new_records(K)
+    for r in range(3):
+        eng.rollout(K, policy_seed=4, records=rec)
+        oact, obs, mask, meta, eplen = ora.rollout(K, 4, threads=THREADS, record_obs=True)
+        v = eng.split(rec)
+        np.testing.assert_array_equal(v.action.cpu().numpy(), oact.astype(np.int8))
+        np.testing.assert_array_equal(v.observations.cpu().numpy(), obs)
+        np.testing.assert_array_equal(v.action_mask.cpu().numpy(), mask)
+        np.testing.assert_array_equal(v.done.cpu().numpy(), meta[..., 2])
+        np.testing.assert_array_equal(v.status.cpu().numpy(), meta[..., 3])
+    c, oc = eng.counters(), ora.counters()
+    for k in ("steps", "episodes", "resets", "sum_len"):
+        assert c[k] == oc[k], (k, c[k], oc[k])
+    assert c["resets"] > B and c["waits"] == c["resets"], (c["resets"], c["waits"])  # nothing was ever dealt ahead
+    for g in (0, 1, 63, 64, 200, B - 1):
+        key, pos = eng.rng_get(g)
+        r = ora.game(g).rng
+        okey, opos = np.array(list(r.mt), dtype=np.uint32), int(r.idx)
+        assert pos == opos, (g, pos, opos)
+        np.testing.assert_array_equal(key, okey, err_msg=f"stream of game {g}")
     eng.close()
 
 

@@ -58,7 +58,10 @@ def test_host_half_of_the_c_abi_under_ubsan():
         import pytest
         pytest.skip("clang's shared UBSan runtime is not in this image")
     so = build.build_ubsan_host()
-    env = dict(os.environ, SKYJO_LIB=so, UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", LD_PRELOAD=rt)
+    # (the child sees no GPU wherever the suite runs - the last refusal it checks is the missing device itself - and sanitizers
+    # run on the host half only: GPU sanitizers are not available on this pool)
+    env = dict(os.environ, SKYJO_LIB=so, UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1", LD_PRELOAD=rt,
+               HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     out = subprocess.run([sys.executable, "-c", _HOST_CALLS.format(root=ROOT)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "HOST-HALF-OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
     assert "runtime error" not in out.stderr
