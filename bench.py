@@ -302,8 +302,10 @@ def main():
     ap.add_argument("--rng", choices=["mt19937", "philox"], default="mt19937")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short blocks of the other BASELINE configurations")
-    ap.add_argument("--no-records", action="store_true", help="do not write records (not the headline)")
+    ap.add_argument("--no-records", action="store_true", default=bool(os.environ.get("SKYJO_BENCH_NO_RECORDS")), help="do not write records (not the headline)")
     ap.add_argument("--actions-array", action="store_true", help="also write the int32 action array (the action is byte D of every record anyway)")
+    ap.add_argument("--record-layout", choices=["row-major", "tile-planar"], default=os.environ.get("SKYJO_BENCH_RECORD_LAYOUT", "row-major"),
+                    help="how the fused rollout lays out its records (include/skyjo_vec.h: SKYJO_OPT_RECORD_LAYOUT)")
     ap.add_argument("--direct-obs", action="store_true", help="observe_other_player_indirect=False: D = 19 + 12 N (not the headline)")
     args = ap.parse_args()
 
@@ -355,7 +357,10 @@ def main():
         CHUNK = eng.deal_interval() * CYCLES_PER_LAUNCH  # ... or ONE launch of k_cycle over several (the tiles stay in LDS between them)
     D = eng.obs_dim
     record = not args.no_records
-    rec = eng.new_records(CHUNK) if record else None           # [CHUNK, B, 64] ring reused by every launch
+    planar = args.record_layout == "tile-planar"
+    if planar:
+        eng.set_record_layout("tile-planar")
+    rec = (eng.new_planar_records(CHUNK) if planar else eng.new_records(CHUNK)) if record else None  # [CHUNK, B, 64] ring reused by every launch
     act = torch.empty((CHUNK, B), dtype=torch.int32, device=dev) if args.actions_array else None
 
     def run(launches):

@@ -87,6 +87,7 @@ SIGNATURES = {
     "skyjo_vec_rollout": (C.c_int, [VP, I32, U64, VP, VP, VP]),
     "skyjo_vec_observe": (C.c_int, [VP, VP, VP, VP]),
     "skyjo_vec_unpack": (C.c_int, [VP, VP, I64, VP, VP, VP, VP, VP, VP, VP]),
+    "skyjo_vec_unpack_tiles": (C.c_int, [VP, VP, I64, VP, VP, VP, VP, VP, VP, VP]),
     "skyjo_vec_sample_actions": (C.c_int, [VP, VP, VP, I64, U64, U64, I32, VP, VP, VP, VP]),
     "skyjo_vec_mlp_create": (C.c_int, [I32, I32, I32, I32, VP, VP, VP, VP, VP, VP, C.POINTER(VP)]),
     "skyjo_vec_mlp_destroy": (C.c_int, [VP]),

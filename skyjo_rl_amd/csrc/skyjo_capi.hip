@@ -130,6 +130,7 @@ struct skyjo_vec {
   uint8_t *hm_mask_d = nullptr, *hm_records_d = nullptr, *hm_raw_d = nullptr;
   int raw_stride = 0;
   uint32_t host_seq = 0;  // sequence number of the last host-style step of a single-tile engine (see skyjo_vec_step_host)
+  bool rec_planar = false;  // SKYJO_OPT_RECORD_LAYOUT: skyjo_vec_rollout writes its records tile-planar (one-kernel form, indirect observation)
   bool no_bank = false;  // SKYJO_OPT_NO_BANK: no pre-dealt episodes, every deal is made in place from the stream's position
   // lazily allocated scratch for the *_host conveniences
   int32_t *d_actions = nullptr;
@@ -382,16 +383,19 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
     if (const char *e = getenv("SKYJO_CYCLE_SPLIT")) lds_deal |= (uint32_t)(atoi(e) & 3) << 30;  // diagnostic: 1 = roles by SIMD parity, 2 = by SIMD pair
     const int S = h->cycle_s;
     dim3 cgrid((h->P.tiles + S - 1) / S), cblock(2 * S * SK_TILE);
-#define LAUNCHC(I, NP)                                                                                                                 \
-  hipExtLaunchKernelGGL((k_cycle<I, NP>), cgrid, cblock, (uint32_t)h->lds_cycle, s, e0, e1, 0, h->P, rec, act_out, iters, policy_seed, \
+#define LAUNCHC(I, NP, PL)                                                                                                                 \
+  hipExtLaunchKernelGGL((k_cycle<I, NP, PL>), cgrid, cblock, (uint32_t)h->lds_cycle, s, e0, e1, 0, h->P, rec, act_out, iters, policy_seed, \
                         h->iter, tag, (uint32_t)h->lds_cycle_step, lds_deal, cycle_len)
-    switch (h->P.L.N * 2 + (ind ? 1 : 0)) {
-      case 5: LAUNCHC(true, 2); break;
-      case 7: LAUNCHC(true, 3); break;
-      case 9: LAUNCHC(true, 4); break;
-      case 4: LAUNCHC(false, 2); break;
-      case 6: LAUNCHC(false, 3); break;
-      default: LAUNCHC(false, 4); break;
+    switch (h->P.L.N * 2 + (ind ? 1 : 0) + (ind && h->rec_planar ? 100 : 0)) {
+      case 5: LAUNCHC(true, 2, false); break;
+      case 7: LAUNCHC(true, 3, false); break;
+      case 9: LAUNCHC(true, 4, false); break;
+      case 105: LAUNCHC(true, 2, true); break;
+      case 107: LAUNCHC(true, 3, true); break;
+      case 109: LAUNCHC(true, 4, true); break;
+      case 4: LAUNCHC(false, 2, false); break;
+      case 6: LAUNCHC(false, 3, false); break;
+      default: LAUNCHC(false, 4, false); break;
     }
 #undef LAUNCHC
     HIPCHK(hipGetLastError());
@@ -622,11 +626,13 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     h->lds_cycle = need, h->cycle_s = S;
     h->merged_capable = fits;
     if (fits) {
-      const void *fn = P.L.indirect ? (cfg->num_players == 2 ? (const void *)k_cycle<true, 2> : cfg->num_players == 3 ? (const void *)k_cycle<true, 3> : (const void *)k_cycle<true, 4>)
-                                    : (cfg->num_players == 2 ? (const void *)k_cycle<false, 2> : cfg->num_players == 3 ? (const void *)k_cycle<false, 3> : (const void *)k_cycle<false, 4>);
+      const void *fn = P.L.indirect ? (cfg->num_players == 2 ? (const void *)k_cycle<true, 2, false> : cfg->num_players == 3 ? (const void *)k_cycle<true, 3, false> : (const void *)k_cycle<true, 4, false>)
+                                    : (cfg->num_players == 2 ? (const void *)k_cycle<false, 2, false> : cfg->num_players == 3 ? (const void *)k_cycle<false, 3, false> : (const void *)k_cycle<false, 4, false>);
+      const void *fnp = !P.L.indirect ? nullptr : cfg->num_players == 2 ? (const void *)k_cycle<true, 2, true> : cfg->num_players == 3 ? (const void *)k_cycle<true, 3, true> : (const void *)k_cycle<true, 4, true>;
       // (the attribute belongs to the function, not to the handle: always the whole CU, so that engines of different batch sizes -
       // different S - can live side by side in one process)
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+          (fnp && hipFuncSetAttribute(fnp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)) {
         (void)hipGetLastError();
         h->merged_capable = false;
       }
@@ -924,6 +930,9 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   hipStream_t s = (hipStream_t)stream;
   uint8_t *rec = (uint8_t *)records_out;
+  const bool planar = h->rec_planar;
+  if (planar && rec && !(h->merged && h->P.L.indirect))
+    return fail(SKYJO_E_STATE, "SKYJO_OPT_RECORD_LAYOUT = tile-planar needs the one-kernel dealing form (SKYJO_OPT_OVERLAP 3) and the indirect observation");
   for (int done = 0; done < iters;) {
     int n = iters - done < kMaxRolloutChunk ? iters - done : kMaxRolloutChunk;
     // a launch ends where the next dealing run is due, so the cadence does not depend on how the caller slices its calls
@@ -950,7 +959,7 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
     if (rc) return rc;
     done += n;
     if (run_due && (rc = piped ? start_deals_piped(h, s) : start_deals(h, s))) return rc;
-    if (rec) rec += (size_t)n * h->P.B * h->P.L.rec_bytes;
+    if (rec) rec += (size_t)n * (planar ? h->G : (size_t)h->P.B) * h->P.L.rec_bytes;
     if (actions_out) actions_out += (size_t)n * h->P.B;
   }
   return SKYJO_OK;
@@ -970,8 +979,8 @@ int skyjo_vec_observe(skyjo_vec *h, const int32_t *players, void *records_out, v
   return SKYJO_OK;
 }
 
-int skyjo_vec_unpack(skyjo_vec *h, const void *records, int64_t n, int8_t *obs, int8_t *mask, uint8_t *agent,
-                     uint8_t *phase, uint8_t *done, uint8_t *status, void *stream) {
+static int unpack_impl(skyjo_vec *h, const void *records, int64_t n, int8_t *obs, int8_t *mask, uint8_t *agent, uint8_t *phase, uint8_t *done,
+                       uint8_t *status, void *stream, int planar) {
   if (!h || !records || n < 0) return fail(SKYJO_E_INVALID, "bad argument");
   GUARD(h);
   if (n == 0) return SKYJO_OK;
@@ -979,9 +988,20 @@ int skyjo_vec_unpack(skyjo_vec *h, const void *records, int64_t n, int8_t *obs, 
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h->P.L, (const uint8_t *)records,
-                     (long long)n, obs, mask, agent, phase, done, status);
+                     (long long)n, obs, mask, agent, phase, done, status, planar);
   HIPCHK(hipGetLastError());
   return SKYJO_OK;
+}
+
+int skyjo_vec_unpack(skyjo_vec *h, const void *records, int64_t n, int8_t *obs, int8_t *mask, uint8_t *agent,
+                     uint8_t *phase, uint8_t *done, uint8_t *status, void *stream) {
+  return unpack_impl(h, records, n, obs, mask, agent, phase, done, status, stream, 0);
+}
+
+int skyjo_vec_unpack_tiles(skyjo_vec *h, const void *records, int64_t n_tiles, int8_t *obs, int8_t *mask, uint8_t *agent,
+                           uint8_t *phase, uint8_t *done, uint8_t *status, void *stream) {
+  if (h && (!h->P.L.indirect || h->P.L.rec_bytes != 64)) return fail(SKYJO_E_STATE, "tile-planar records exist for the indirect observation only");
+  return unpack_impl(h, records, n_tiles * SK_TILE, obs, mask, agent, phase, done, status, stream, 1);
 }
 
 const double *skyjo_vec_rewards_ptr(const skyjo_vec *h) { return h ? h->P.rewards : nullptr; }
@@ -1416,6 +1436,7 @@ int skyjo_vec_get_option(const skyjo_vec *h, int option, int64_t *value_out) {
     case SKYJO_OPT_DEAL_INTERVAL: *value_out = h->deal_every_iters; return SKYJO_OK;
     case SKYJO_OPT_OVERLAP: *value_out = h->merged ? 3 : h->overlap ? 2 : 0; return SKYJO_OK;
     case SKYJO_OPT_NO_BANK: *value_out = h->no_bank ? 1 : 0; return SKYJO_OK;
+    case SKYJO_OPT_RECORD_LAYOUT: *value_out = h->rec_planar ? SKYJO_REC_TILE_PLANAR : SKYJO_REC_ROW_MAJOR; return SKYJO_OK;
     default: return fail(SKYJO_E_INVALID, "unknown option");
   }
 }
@@ -1445,6 +1466,12 @@ int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
     case SKYJO_OPT_NO_BANK:
       if (h->seeded) return fail(SKYJO_E_STATE, "SKYJO_OPT_NO_BANK must be set before skyjo_vec_seed");
       h->no_bank = value != 0;
+      return SKYJO_OK;
+    case SKYJO_OPT_RECORD_LAYOUT:
+      if (value != SKYJO_REC_ROW_MAJOR && value != SKYJO_REC_TILE_PLANAR) return fail(SKYJO_E_INVALID, "SKYJO_OPT_RECORD_LAYOUT takes SKYJO_REC_ROW_MAJOR or SKYJO_REC_TILE_PLANAR");
+      if (value == SKYJO_REC_TILE_PLANAR && !(h->merged_capable && h->P.L.indirect))
+        return fail(SKYJO_E_INVALID, "the tile-planar record layout exists for the one-kernel form of the fused rollout (two to four players, indirect observation)");
+      h->rec_planar = value == SKYJO_REC_TILE_PLANAR;
       return SKYJO_OK;
     case SKYJO_OPT_DEBUG_SPIN_LOG2:
       if (value < 1 || value > 30) return fail(SKYJO_E_INVALID, "spin limit must be 2^1 .. 2^30");

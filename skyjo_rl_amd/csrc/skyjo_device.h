@@ -1228,7 +1228,11 @@ __device__ __forceinline__ uint32_t sk_next_tag(uint32_t t) {
   t = (t + 1u) & 0x7fffffffu;
   return t ? t : 1u;
 }
-template <bool INDIRECT, bool POLICY, int NP>
+// PLANAR (the fused rollout of k_cycle, indirect observation): the records leave in the tile-planar layout (include/skyjo_vec.h,
+// SKYJO_OPT_RECORD_LAYOUT) - piece p (16 bytes) of lane l's record at  block + p * 1024 + l * 16  of the tile's 4 KiB block - so every
+// store instruction writes 1 KiB contiguously STRAIGHT FROM THE REGISTERS the record was assembled in: no LDS staging, no
+// read-back, no wait between assembling a record and the next iteration.
+template <bool INDIRECT, bool POLICY, int NP, bool PLANAR = false>
 __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, const int lane, uint32_t *lds_raw, const int32_t *actions,
                                           uint8_t *rec_out, int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0,
                                           double *end_rew_out, uint8_t *end_out, uint8_t *raw_out, int raw_stride, const int cycle_len = 0,
@@ -1362,8 +1366,15 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
         if (INDIRECT) {  // staged in LDS, written by the whole wavefront below
           uint4 rr[4];
           emit_record<INDIRECT>(P, lp, h, ob, a, nullptr, rr, &rec_a, rec_b);
+          if (PLANAR) {  // (a partial last tile: the lanes without a game are switched off here, their slots stay as they were)
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            uint8_t *blk = rec_out + ((size_t)it * P.tiles + (size_t)tile) * (SK_TILE * 64) + lane * 16;
 #pragma unroll
-          for (int p = 0; p < 4; p++) *(uint4 *)(stg + lane * 64 + ((p + (lane >> 1)) & 3) * 16) = rr[p];
+            for (int p = 0; p < 4; p++) __builtin_nontemporal_store((u32x4_t){rr[p].x, rr[p].y, rr[p].z, rr[p].w}, (u32x4_t *)(blk + p * 1024));
+          } else {
+#pragma unroll
+            for (int p = 0; p < 4; p++) *(uint4 *)(stg + lane * 64 + ((p + (lane >> 1)) & 3) * 16) = rr[p];
+          }
         } else {  // direct observation: rec_bytes = 80 / 96 / 112 ...; staged record-major with a stride that spreads the banks
           emit_record<INDIRECT>(P, lp, h, ob, a, stg + lane * sk_stage_stride(P.L.rec_bytes), nullptr, &rec_a, rec_b);
         }
@@ -1418,7 +1429,7 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
         }
       }
     }
-    if (INDIRECT && rec_out) {
+    if (INDIRECT && !PLANAR && rec_out) {
       // The 64 records of the tile are one contiguous 4 KiB block of the output.  They pass through LDS so that each
       // store instruction writes 1 KiB of it contiguously - full lines, one request per 64 bytes, instead of 64 pieces
       // of 16 bytes at a 64-byte stride - and they are written non-temporally: the records are a stream nobody on
@@ -2413,7 +2424,7 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
 // are claimed through LDS counters; nothing depends on how the hardware spreads the wavefronts.
 // ------------------------------------------------------------------------------------------
 #define SK_CYCLE_MAX_S 4
-template <bool INDIRECT, int NP>
+template <bool INDIRECT, int NP, bool PLANAR>
 __global__ __launch_bounds__(2 * SK_CYCLE_MAX_S *SK_TILE) void k_cycle(SkParams Pin, uint8_t *rec_out, int32_t *act_out, int iters, uint64_t policy_seed,
                                                                         uint64_t iter0, uint32_t deal_tag_run, uint32_t lds_step_bytes,
                                                                         uint32_t lds_deal_bytes, int cycle_len) {
@@ -2451,7 +2462,7 @@ __global__ __launch_bounds__(2 * SK_CYCLE_MAX_S *SK_TILE) void k_cycle(SkParams 
   }
   Pin.wg_local = 1u;  // the games of tile `unit` are dealt by dealing slot `slot` of THIS workgroup: hand-overs stay inside the CU
   if (role == 0) {
-    step_body<INDIRECT, true, NP>(Pin, unit, lane, lds_raw + (size_t)slot * (lds_step_bytes >> 2), nullptr, rec_out, act_out, iters, policy_seed, iter0,
+    step_body<INDIRECT, true, NP, PLANAR>(Pin, unit, lane, lds_raw + (size_t)slot * (lds_step_bytes >> 2), nullptr, rec_out, act_out, iters, policy_seed, iter0,
                                   nullptr, nullptr, nullptr, 0, cycle_len, NP >= 4 ? true : defer_ok);  // (four players: never without - the host does not ask for it)
   } else {
     // the run the previous launch planned (deal_tag_run, 0 = none), then - a launch of several dealing cycles - the runs its step
@@ -2589,26 +2600,31 @@ __global__ void k_episode_ends(SkParams P, const uint8_t *rec, double *rew_out, 
   for (int p = 0; p < P.L.N; p++) rew_out[(size_t)g * P.L.N + p] = end ? P.rewards[(size_t)g * P.L.N + p] : 0.0;
 }
 
-// records -> the reference's dense arrays (obs int8[n][D], mask int8[n][26], ...)
+// records -> the reference's dense arrays (obs int8[n][D], mask int8[n][26], ...).  `planar`: the records lie tile-planar
+// (SKYJO_REC_TILE_PLANAR: byte k of record r at  (r / 64) * 4096 + (k / 16) * 1024 + (r % 64) * 16 + k % 16; 64-byte records).
+__device__ __forceinline__ const uint8_t *sk_rec_byte(const uint8_t *rec, long long r, int k, int rec_bytes, int planar) {
+  return planar ? rec + (r >> 6) * 4096 + (long long)(k >> 4) * 1024 + (r & 63) * 16 + (k & 15) : rec + r * rec_bytes + k;
+}
 __global__ void k_unpack(SkLayout L, const uint8_t *rec, long long n, int8_t *obs, int8_t *mask, uint8_t *agent,
-                         uint8_t *phase, uint8_t *done, uint8_t *status) {
+                         uint8_t *phase, uint8_t *done, uint8_t *status, int planar) {
   const long long total = n * (long long)(L.D + 26);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / (L.D + 26);
     const int k = (int)(i % (L.D + 26));
-    const uint8_t *src = rec + r * L.rec_bytes;
+#define SRC(b) (*sk_rec_byte(rec, r, (b), L.rec_bytes, planar))
     if (k < L.D) {
-      if (obs) obs[r * L.D + k] = (int8_t)src[k];
+      if (obs) obs[r * L.D + k] = (int8_t)SRC(k);
     } else {
-      if (mask) mask[r * 26 + (k - L.D)] = (int8_t)src[L.Dp + (k - L.D)];
+      if (mask) mask[r * 26 + (k - L.D)] = (int8_t)SRC(L.Dp + (k - L.D));
     }
     if (k == 0) {
-      if (agent) agent[r] = src[L.Dp + 26];
-      if (phase) phase[r] = src[L.Dp + 27];
-      if (done) done[r] = src[L.Dp + 28];
-      if (status) status[r] = src[L.Dp + 29];
+      if (agent) agent[r] = SRC(L.Dp + 26);
+      if (phase) phase[r] = SRC(L.Dp + 27);
+      if (done) done[r] = SRC(L.Dp + 28);
+      if (status) status[r] = SRC(L.Dp + 29);
     }
+#undef SRC
   }
 }
 

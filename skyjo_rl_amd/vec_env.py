@@ -113,6 +113,36 @@ class SkyjoVecEnv:
         return self._torch().empty((*lead, self.num_envs, self.record_bytes), dtype=self._torch().uint8,
                                    device=self._dev())
 
+    # ------------------------------------------------------------------ tile-planar records of the fused rollout
+    @property
+    def tiles(self):
+        return (self.num_envs + 63) // 64
+
+    def set_record_layout(self, layout):
+        """'row-major' (default) or 'tile-planar' (include/skyjo_vec.h: SKYJO_OPT_RECORD_LAYOUT): how ``rollout`` lays out its
+        records.  Tile-planar records come as ``new_planar_records(iters)`` = uint8 [iters, tiles, 4, 64, 16]."""
+        _lib.check(self._L.skyjo_vec_set_option(self._h, 6, {"row-major": 0, "tile-planar": 1}[layout]))
+        self.record_layout = layout
+
+    def new_planar_records(self, iters):
+        assert self.record_bytes == 64
+        return self._torch().empty((iters, self.tiles, 4, 64, 16), dtype=self._torch().uint8, device=self._dev())
+
+    def rows_from_planar(self, records):
+        """Row-major copy [iters, num_envs, 64] of tile-planar records (``split`` / ``unpack`` take it from there)."""
+        it, t = records.shape[0], records.shape[1]
+        return records.permute(0, 1, 3, 2, 4).reshape(it, t * 64, 64)[:, :self.num_envs]
+
+    def unpack_tiles(self, records):
+        """Dense obs int8[n, D], mask int8[n, 26] straight from tile-planar blocks (n = 64 x number of blocks)."""
+        torch = self._torch()
+        nt = records.numel() // 4096
+        obs = torch.empty((nt * 64, self.obs_dim), dtype=torch.int8, device=self._dev())
+        mask = torch.empty((nt * 64, 26), dtype=torch.int8, device=self._dev())
+        _lib.check(self._L.skyjo_vec_unpack_tiles(self._h, C.c_void_p(records.data_ptr()), nt, C.c_void_p(obs.data_ptr()),
+                                                  C.c_void_p(mask.data_ptr()), None, None, None, None, self._stream()))
+        return obs, mask
+
     def split(self, records):
         """Zero-copy views of a records tensor: the reference's {"observations","action_mask"} + meta."""
         torch = self._torch()
@@ -166,7 +196,8 @@ class SkyjoVecEnv:
         rp = C.c_void_p(records.data_ptr()) if records is not None else None
         ap = C.c_void_p(actions.data_ptr()) if actions is not None else None
         if records is not None:
-            assert records.is_contiguous() and records.numel() == iters * self.num_envs * self.record_bytes
+            per_it = self.tiles * 64 if getattr(self, "record_layout", "row-major") == "tile-planar" else self.num_envs
+            assert records.is_contiguous() and records.numel() == iters * per_it * self.record_bytes
         if actions is not None:
             assert actions.is_contiguous() and actions.numel() == iters * self.num_envs
         _lib.check(self._L.skyjo_vec_rollout(self._h, int(iters), int(policy_seed), rp, ap, self._stream()))

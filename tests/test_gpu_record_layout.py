@@ -1,0 +1,77 @@
+"""The tile-planar record layout of the fused rollout (include/skyjo_vec.h: SKYJO_OPT_RECORD_LAYOUT): the same
+records, cut into 16-byte pieces so that the step wavefront stores them straight from its registers.  Two engines with the same
+seeds, one per layout: every byte of every record equal (bit-equality of the unpacked records), through the torch view and through
+skyjo_vec_unpack_tiles; the row-major engine itself is pinned to the oracle by tests/test_gpu_full_batch.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # name                     B      N  cycles per launch, launches
+    ("headline_eight_cycles", 65536, 3, 8, 2),
+    ("cfg2_eight_cycles", 4096, 2, 8, 3),
+    ("cfg4_shard_S2", 32768, 3, 4, 2),
+    ("N4_S3", 49152, 4, 2, 2),
+    ("partial_tile_partial_wg", 40010, 2, 4, 2),
+    ("single_cycle_calls", 16400, 3, 1, 5),
+]
+
+
+@pytest.mark.parametrize("name,B,N,cycles,launches", CASES, ids=[c[0] for c in CASES])
+def test_tile_planar_records_equal_row_major_records(name, B, N, cycles, launches):
+    import torch
+    from skyjo_rl_amd import SkyjoVecEnv
+
+    cfg = dict(num_players=N, auto_reset=True)
+    a, b = SkyjoVecEnv(B, **cfg), SkyjoVecEnv(B, **cfg)
+    assert a.dealing_form() == "one kernel"
+    b.set_record_layout("tile-planar")
+    for e in (a, b):
+        e.set_deal_interval(e.deal_interval())
+        e.seed(None, 11)
+    K = cycles * a.deal_interval()
+    ra, rb = a.new_records(K), b.new_planar_records(K)
+    rb.fill_(0xEE)
+    for r in range(launches):
+        a.rollout(K, policy_seed=3, records=ra)
+        b.rollout(K, policy_seed=3, records=rb)
+        rows = b.rows_from_planar(rb)
+        assert rows.shape == ra.shape
+        assert torch.equal(rows, ra), f"{name}: launch {r}: {(rows != ra).sum().item()} bytes differ"
+        # the dense arrays straight from the planar blocks == the row-major engine's
+        obs_t, mask_t = b.unpack_tiles(rb)
+        obs_r, mask_r = a.unpack(ra)
+        G = b.tiles * 64
+        assert torch.equal(obs_t.view(K, G, -1)[:, :B], obs_r.view(K, B, -1))
+        assert torch.equal(mask_t.view(K, G, 26)[:, :B], mask_r.view(K, B, 26))
+    if B % 64:  # the slots of the partial last tile beyond num_envs are never written
+        pad = rb.permute(0, 1, 3, 2, 4).reshape(K, b.tiles * 64, 64)[:, B:]
+        assert bool((pad == 0xEE).all())
+    ca, cb = a.counters(), b.counters()
+    for k in ("steps", "episodes", "resets", "sum_len", "waits"):
+        assert ca[k] == cb[k], (k, ca[k], cb[k])
+    assert ca["episodes"] > 0
+    a.close(), b.close()
+
+
+def test_the_layout_option_is_refused_where_the_kernel_does_not_exist():
+    from skyjo_rl_amd import SkyjoNativeError, SkyjoVecEnv
+
+    e = SkyjoVecEnv(256, num_players=3, observe_other_player_indirect=False)
+    with pytest.raises(SkyjoNativeError):
+        e.set_record_layout("tile-planar")  # direct observation: wider records
+    e.close()
+    e = SkyjoVecEnv(256, num_players=5)
+    with pytest.raises(SkyjoNativeError):
+        e.set_record_layout("tile-planar")  # generic player count: no one-kernel form
+    e.close()
+    e = SkyjoVecEnv(256, num_players=3)
+    e.set_record_layout("tile-planar")
+    e.set_overlap(0)  # dealing in line: the step kernel of that form writes row-major records only
+    e.seed(None, 0)
+    with pytest.raises(SkyjoNativeError):
+        e.rollout(8, records=e.new_planar_records(8))
+    e.set_record_layout("row-major")
+    e.rollout(8, records=e.new_records(8))
+    e.close()

@@ -7,9 +7,17 @@ from skyjo_rl_amd import SkyjoVecEnv, _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 eng = SkyjoVecEnv(B, num_players=3)
 eng.seed(None, 0)
-ITERS = 80
-rec = eng.new_records(ITERS); act = torch.empty((ITERS, B), dtype=torch.int32, device="cuda")
-if len(sys.argv) > 2 and sys.argv[2] == "norec": rec = act = None
+eng.set_deal_interval(eng.deal_interval())
+ITERS = eng.deal_interval() * int(os.environ.get("CYCLES", "8"))  # one k_cycle launch of that many dealing cycles
+mode = sys.argv[2] if len(sys.argv) > 2 else "rec"
+act = None
+if mode == "planar":
+    eng.set_record_layout("tile-planar"); rec = eng.new_planar_records(ITERS)
+elif mode == "norec":
+    rec = None
+else:
+    rec = eng.new_records(ITERS)
+print("mode", mode, "iterations per launch", ITERS, "form", eng.dealing_form())
 for _ in range(20): eng.rollout(ITERS, 1, records=rec, actions=act)
 torch.cuda.synchronize()
 out = np.zeros(16, dtype=np.uint64)
