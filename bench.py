@@ -55,13 +55,13 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (the guide's figure without sparsity)
 CHUNK = int(os.environ.get("SKYJO_BENCH_CHUNK", "0"))  # lockstep iterations per kernel launch; 0 = the engine's dealing interval
-CYCLES_PER_LAUNCH = int(os.environ.get("SKYJO_BENCH_CYCLES", "8"))  # dealing cycles per launch of the one-kernel form (k_cycle)
+CYCLES_PER_LAUNCH = int(os.environ.get("SKYJO_BENCH_CYCLES", "16"))  # dealing cycles per launch of the one-kernel form (k_cycle): the ABI's maximum
 SETTLE = int(os.environ.get("SKYJO_BENCH_SETTLE", "100"))  # launches between seeding and the warm-up (see main)
 # the reference's own Python loop (core loop + policy_ra, N = 3, indirect observation), measured in the
 # build container (8-core Xeon 2.1 GHz); the reference cannot travel to the GPU box, so these are constants
 REFERENCE_STEPS_PER_S_1_CORE = 8.3e3
 REFERENCE_STEPS_PER_S_8_CORES = 52.8e3
-TRAFFIC_PROFILE = os.path.join("profiles", "r4_hbm_traffic.json")  # rocprofv3 PMC passes of this very launch shape (tools/refresh_profiles.sh)
+TRAFFIC_PROFILE = os.path.join("profiles", "r5_hbm_traffic.json")  # rocprofv3 PMC passes of this very launch shape (tools/refresh_profiles.sh)
 KERNEL_SOURCES = ("skyjo_rl_amd/csrc/skyjo_device.h", "skyjo_rl_amd/csrc/skyjo_capi.hip", "skyjo_rl_amd/csrc/skyjo_layout.h")
 
 

@@ -3,7 +3,7 @@
 import collections, csv, glob, json, os, shutil, sys
 sys.path.insert(0, os.getcwd())
 src, dst = "gpurun_out/final", "profiles"
-R = sys.argv[1] if len(sys.argv) > 1 else "r4"
+R = sys.argv[1] if len(sys.argv) > 1 else "r5"
 def find(pat):  # newest match: gpurun merges every refresh into the same local directory
     r = sorted(glob.glob(os.path.join(src, pat), recursive=True), key=os.path.getmtime)
     return r[-1] if r else None
@@ -73,6 +73,37 @@ if "ea" in pmc and ks in pmc["ea"]:  # the same kernel at the fabric: read reque
         traffic["k_deal_fabric"] = {"read_bytes": int(e["TCC_EA0_RDREQ_128B_sum"] * 128 + (e["TCC_EA0_RDREQ_sum"] - e["TCC_EA0_RDREQ_128B_sum"]) * 64),
                                     "write_bytes": int(e["TCC_EA0_WRREQ_64B_sum"] * 64 + (e["TCC_EA0_WRREQ_sum"] - e["TCC_EA0_WRREQ_64B_sum"]) * 32)}
 json.dump(traffic, open(os.path.join(dst, R + "_hbm_traffic.json"), "w"), indent=1)
+# attribution passes (tools/refresh_profiles.sh): the same launch with counter-based deals / without records
+def side_pmc(prefix):
+    out = {}
+    for tag in ("fetch", "write", "ea"):
+        f = find("%s_pmc_%s/**/*counter_collection.csv" % (prefix, tag))
+        if not f:
+            continue
+        agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if k.startswith("k_cycle") or k.startswith("k_step"):
+                agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
+        for k in agg:
+            out.setdefault(k, {}).update({c: v / len(n[k]) for c, v in agg[k].items()})
+            out[k]["dispatches_" + tag] = len(n[k])
+    res = {}
+    for k, e in out.items():
+        d = dict(e)
+        if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            d["bytes_per_launch"] = int(round((2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024))
+            d["read_bytes_per_launch"], d["write_bytes_per_launch"] = int(round(2 * e["FETCH_SIZE"] * 1024)), int(round(e["WRITE_SIZE"] * 1024))
+        if "TCC_EA0_RDREQ_sum" in e:
+            rd128, rd, wr64, wr = e["TCC_EA0_RDREQ_128B_sum"], e["TCC_EA0_RDREQ_sum"], e["TCC_EA0_WRREQ_64B_sum"], e["TCC_EA0_WRREQ_sum"]
+            d["fabric_read_bytes"], d["fabric_write_bytes"] = int(rd128 * 128 + (rd - rd128) * 64), int(wr64 * 64 + (wr - wr64) * 32)
+        res[k] = d
+    return res
+attr = {"note": "per dispatch of the dominant kernel, bench.py's launch shape (tools/refresh_profiles.sh); FETCH_SIZE doubled as in " + R + "_hbm_traffic.json",
+        "mt19937_records": {"bytes_per_launch": traffic["k_step_bytes_per_launch"], "read_bytes_per_launch": int(round(2 * fk * 1024)),
+                            "write_bytes_per_launch": int(round(wk * 1024)), "fabric": traffic.get("fabric")},
+        "philox_records": side_pmc("philox"), "mt19937_no_records": side_pmc("norec")}
+json.dump(attr, open(os.path.join(dst, R + "_hbm_traffic_attribution.json"), "w"), indent=1)
 # config 5
 c5 = os.path.join(src, "cfg5.json")
 if os.path.exists(c5):

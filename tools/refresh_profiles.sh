@@ -16,6 +16,17 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVES SQ_WAVE_CYCLES SQ
   set -- $pass; tag=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/pmc_$tag" -- python3 "$root/bench.py" --steps 30 --warmup 10 --blocks 1 --no-cpu-baseline --no-other-configs > "$out/pmc_$tag.json" 2> "$out/pmc_$tag.err"; echo "pmc $tag rc=$?"
 done
+# the same launch with counter-based deals (no generator state at all): FETCH_SIZE / WRITE_SIZE / fabric requests - what is left is
+# records + tiles + bank; the difference to the passes above is what the numpy-exact generator moves (EXPERIMENTS.md round 5)
+for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+  set -- $pass; tag=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/philox_pmc_$tag" -- python3 "$root/bench.py" --rng philox --steps 30 --warmup 10 --blocks 1 --no-cpu-baseline --no-other-configs > "$out/philox_pmc_$tag.json" 2> "$out/philox_pmc_$tag.err"; echo "philox pmc $tag rc=$?"
+done
+# ... and without records (the step wavefronts store nothing per iteration): tiles + bank + generator
+for pass in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
+  set -- $pass; tag=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/norec_pmc_$tag" -- python3 "$root/bench.py" --no-records --steps 30 --warmup 10 --blocks 1 --no-cpu-baseline --no-other-configs > "$out/norec_pmc_$tag.json" 2> "$out/norec_pmc_$tag.err"; echo "norec pmc $tag rc=$?"
+done
 # config 5 (65 536 x 4 players, the action-mask model on the matrix cores picks every action): bench line + kernel stats
 cd "$root"
 python3 tools/bench_cfg5.py 65536 64 8 > "$out/cfg5.json" 2> "$out/cfg5.err"; echo "cfg5 rc=$?"
