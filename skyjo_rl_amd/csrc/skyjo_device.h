@@ -214,6 +214,35 @@ __device__ __forceinline__ void dma_record(const uint8_t *base, uint32_t voff, u
     base += 1024, lds += 1024;
   }
 }
+// The BANK of pre-dealt episodes is game-major (round 5): the record of (slot, game) is `chunks` consecutive 16-byte pieces, so that
+// the ONE lane that takes it reads three 128-byte lines, every byte of them used - in the tile layout its 18 pieces lay 1 KiB apart,
+// 18 lines fetched for 288 bytes: 1.0 GB of the 10.1 GB a launch of 1 024 iterations moved (profiles/r5_hbm_traffic_attribution.json).
+// The LDS side is still the lane's column (chunk c at lds_tile + c * 1024 + lane * 16) and the LDS-DMA adds its immediate offset to
+// BOTH addresses: chunk c goes out with offset 16 c and M0 = row c's base - 16 c, i.e. M0 moves on by 1024 - 16 per chunk.
+#define SK_DMAB4(NT)                                                                                                        \
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" NT "\n\t"                \
+               "s_add_u32 m0, m0, 0x3f0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:16" NT "\n\t"                   \
+               "s_add_u32 m0, m0, 0x3f0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:32" NT "\n\t"                   \
+               "s_add_u32 m0, m0, 0x3f0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:48" NT "\n\t"                   \
+               "s_mov_b32 m0, %0"                                                                                           \
+               : "=&s"(keep)                                                                                                \
+               : "v"(voff), "s"(base), "s"(lds)                                                                             \
+               : "memory", "scc")
+template <bool NT>
+__device__ __forceinline__ void dma_bank_record(const uint8_t *base, uint32_t voff, uint32_t lds, int chunks) {
+  uint32_t keep;
+  int c = 0;
+  for (; c + 4 <= chunks; c += 4) {
+    if (NT) SK_DMAB4(" nt");
+    else SK_DMAB4("");
+    base += 64, lds += 4096;
+  }
+  for (; c < chunks; c++) {
+    if (NT) SK_DMA1(" nt");
+    else SK_DMA1("");
+    base += 16, lds += 1024;
+  }
+}
 // every vector-memory operation this wavefront has issued so far is complete (the LDS-DMA data is in LDS)
 __device__ __forceinline__ void sk_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -1064,8 +1093,34 @@ __device__ __forceinline__ void emit_record(const SkParams &P, uint8_t *lp, cons
 // ------------------------------------------------------------------------------------------
 // Take the pre-dealt next episode (SkyjoGame.reset, skyjo.py:52-74; the dealing itself is k_deal).
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t bank_rec16(const SkParams &P, int slot, int g) {  // first 16-byte piece of the bank record (slot, game)
+  return ((size_t)slot * P.tiles * SK_TILE + (size_t)g) * P.L.chunks;
+}
 __device__ __forceinline__ void load_spare(const SkParams &P, uint8_t *lp, int slot, int tile, int lane) {
-  tile_load(P, P.spare + (size_t)slot * P.tiles * P.L.chunks * SK_TILE, tile, lane, lp);
+  const uint4 *s = P.spare + bank_rec16(P, slot, tile * SK_TILE + lane);
+  const int n = P.L.chunks;
+  for (int c = 0; c < n; c += 6) {  // (groups of six as in tile_load: one memory round trip per group)
+    uint4 v[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (c + k < n) v[k] = s[c + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (c + k < n) LQ(c + k) = v[k];
+  }
+}
+__device__ __forceinline__ void store_spare(const SkParams &P, uint8_t *lp, int slot, int g) {  // the lane's record in LDS -> its bank slot
+  uint4 *d = P.spare + bank_rec16(P, slot, g);
+  const int n = P.L.chunks;
+  for (int c = 0; c < n; c += 6) {
+    uint4 v[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (c + k < n) v[k] = LQ(c + k);
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (c + k < n) d[c + k] = v[k];
+  }
 }
 
 __device__ __forceinline__ void bank_advance(const SkParams &P, uint8_t *lp, int g, int head, uint32_t dc) {
@@ -1106,9 +1161,9 @@ __device__ __forceinline__ void spare_issue(const SkParams &P, uint8_t *lp, uint
   r.head = LB(H_BANK) % SK_BANK;  // (read before the record is overwritten)
   r.ready = P.spare_ready[(size_t)r.head * G + g];
   r.dc = P.deals_consumed[g];
-  const uint32_t voff = (uint32_t)((((size_t)r.head * P.tiles + tile) * P.L.chunks * SK_TILE + lane) * 16);
+  const uint32_t voff = (uint32_t)(bank_rec16(P, r.head, g) * 16);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the old record has returned
-  dma_record<false>((const uint8_t *)P.spare, voff, lds_tile, P.L.chunks);
+  dma_bank_record<false>((const uint8_t *)P.spare, voff, lds_tile, P.L.chunks);
 }
 __device__ __forceinline__ bool spare_commit(const SkParams &P, uint8_t *lp, int g, const SpareRegs &r) {
   sk_vm_drain();
@@ -2044,7 +2099,7 @@ __device__ __forceinline__ void deal_compact(const SkParams &P, uint32_t *lds_ra
   setb(H_MINSUM, (uint32_t)(ms < 127 ? ms : 127)), setb(H_MINHID, 10);
 #pragma unroll
   for (int c = 0; c < 20; c++)
-    if (4 * c < nwords) dst[(size_t)c * SK_TILE] = make_uint4(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]);
+    if (4 * c < nwords) dst[c] = make_uint4(rec[4 * c], rec[4 * c + 1], rec[4 * c + 2], rec[4 * c + 3]);
 }
 #undef DKW
 
@@ -2333,7 +2388,7 @@ __device__ __forceinline__ void deal_body(const SkParams &P, int list_sel, int p
     act = owner > 0;  // (an entry whose game is not marked busy would be a stale list: never dealt)
     slot = act ? owner - 1 : 0;
   }
-  uint4 *dst = P.spare + ((size_t)slot * P.tiles + g / SK_TILE) * P.L.chunks * SK_TILE + g % SK_TILE;
+  uint4 *dst = P.spare + bank_rec16(P, slot, g);  // (game-major: the record's pieces are consecutive)
   bool mt_overrun = false;
   if (P.rng_mode == SKYJO_RNG_MT19937) {
     // The stream advances in place; the position it had before this deal is kept with the slot so that a mid-game
@@ -2386,7 +2441,7 @@ __device__ __forceinline__ void deal_body(const SkParams &P, int list_sel, int p
     }
   }
   if (act) {
-    if (NP == 0) tile_store(P, P.spare + (size_t)slot * P.tiles * P.L.chunks * SK_TILE, g / SK_TILE, g % SK_TILE, lp);
+    if (NP == 0) store_spare(P, lp, slot, g);
     STAMP(4);
   }
   if (publish_inline == 1 || publish_inline == 2) {
