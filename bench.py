@@ -3,14 +3,16 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3|4] [--blocks R] [--no-other-configs]
 
-A bench "step" is ONE FUSED LAUNCH of the hot path over the whole batch: `iterations_per_step` (88)
-lockstep iterations - in each of them every live game applies one action chosen by the on-device
-random admissible policy (state transition + observation / action-mask build, the 64-byte record
-with the applied action written to HBM) and finished games take their next deal - plus the dealing
-run (k_deal) that the engine starts once per 88 iterations.  So `--steps 20 --warmup 5` are 1 760
-timed lockstep iterations after 440 untimed ones (about 16 episodes per game inside a timed block).
-Before the warm-up the freshly seeded games are run for 100 launches (set-up: seeded together they
-end their first episodes together, EXPERIMENTS.md round 2).
+A bench "step" is ONE FUSED LAUNCH of the hot path over the whole batch: `iterations_per_step` lockstep
+iterations (1 024 at the headline size: sixteen dealing cycles of 64 in one launch of k_cycle) - in each of them
+every live game applies one action chosen by the on-device random admissible policy (state transition +
+observation / action-mask build, the 64-byte record with the applied action written to HBM) and finished games
+take their next deal - with the dealing runs of those cycles inside the same launch (its dealing wavefronts).
+So `--steps 20 --warmup 5` are 20 480 timed lockstep iterations after 5 120 untimed ones (about 190 episodes per
+game inside a timed block).  Before the warm-up the freshly seeded games are run for 100 launches (set-up:
+seeded together they end their first episodes together, EXPERIMENTS.md round 2).  Records are written in the
+tile-planar layout wherever that kernel exists (`--record-layout`; the row-major form of the same launch is
+`other_configs.row_major_records_65536x3`).
 
 Workload (`--config 3`, the default): BASELINE.json configs[2], 65 536 parallel 3-player games per GPU
 (weak scaling under --gpus N), DEFAULT_CONFIG (indirect observation, D = 31), game g seeded base + g,
@@ -28,9 +30,10 @@ than GPUs the run is refused unless SKYJO_BENCH_SHARED_GPU=1 (rehearsal: ranks s
 the statistics record).
 
 Extra objects on the same line:
-  roofline       dominant kernel (k_step, fused rollout) timed with HIP events on its launch stream
-  roofline_path  the whole path (k_step + k_deal per dealing cycle): kernel-time sum from the same events,
-                 and the wall time of the timed region
+  roofline       dominant kernel (k_cycle: step AND dealing wavefronts of sixteen dealing cycles) timed with HIP events
+                 on its launch stream
+  roofline_path  the whole path (= that one kernel in the one-kernel form; k_step + k_deal per dealing cycle in the older
+                 forms): kernel-time sum from the same events, and the wall time of the timed region
   episode_stats  what the ranks all-gather (RCCL): per-seat reward / score statistics
   other_configs  (N = 1) short blocks of the other BASELINE.json configurations in the same run: cfg2 (4 096 x 2),
                  the cfg4 shard (32 768 x 3, game_id0 = 3 * 32 768), cfg5 (65 536 x 4, the action-mask model's policy +
@@ -304,7 +307,7 @@ def other_configs(device, steps, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100, help="fused launches of 88 lockstep iterations per timed block")
+    ap.add_argument("--steps", type=int, default=100, help="fused launches (of `iterations_per_step` lockstep iterations each) per timed block")
     ap.add_argument("--warmup", type=int, default=25, help="untimed launches before the first block")
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps launches each (value = the median block)")
     ap.add_argument("--config", type=int, choices=[3, 4], default=3,
