@@ -1332,6 +1332,9 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
   if (!REGACC)
     for (int k = 0; k < SK_ACC_KINDS * P.L.N; k++) ACC(k) = 0.0;
   STAMP_DECL;
+#ifdef SK_AB_STEP_PRIO  // (A/B builds) the step wavefront ahead of the dealing wavefront it shares its SIMD with
+  __builtin_amdgcn_s_setprio(SK_AB_STEP_PRIO);
+#endif
   // the tile comes in by LDS-DMA as well (non-temporal: it is read once per launch)
   dma_record<true>((const uint8_t *)P.state, (uint32_t)((((size_t)tile * P.L.chunks) * SK_TILE + lane) * 16), lds_tile, P.L.chunks);
   if (P.ov_flags & 1u) sk_publish_deals(P, g);  // (while the tile is on its way)
@@ -2318,6 +2321,9 @@ template <int NP>
 __device__ __forceinline__ void deal_body(const SkParams &P, int list_sel, int publish_inline, const int block, const int lane, uint32_t *lds_raw,
                                           const bool report_health = true) {
   TRACE_DECL;
+#ifdef SK_AB_DEAL_PRIO  // (A/B builds) the dealing wavefront ahead of the step wavefront it shares its SIMD with
+  __builtin_amdgcn_s_setprio(SK_AB_DEAL_PRIO);
+#endif
   uint8_t *lp = (uint8_t *)lds_raw + lane * 16;
   const size_t G = (size_t)P.tiles * SK_TILE;
   const int count = (int)P.deal_count[list_sel];
