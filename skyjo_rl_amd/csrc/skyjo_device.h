@@ -1857,6 +1857,15 @@ struct MtChunkStream {
     const uint32_t lm = live ? 0xffffffffu : 0u;  // (a select the compiler cannot turn into a branch around the tempering)
 #pragma unroll
     for (int k = 0; k < 16; k++) R[k] = __builtin_amdgcn_bitop3_b32(R[k], mt_temper3(v[k]), lm, 0xd8);
+#ifdef SK_AB_OWNER_STORES  // (A/B builds) every lane stores its own chunk: no staging through LDS, four times the write requests
+    if (live) {
+      uint4 *pm = (uint4 *)(mt + c);
+#pragma unroll
+      for (int k = 0; k < 4; k++) pm[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    }
+    issue();
+    return;
+#endif
     uint8_t *row = stg + lane * SK_STG_STRIDE;
 #pragma unroll
     for (int k = 0; k < 4; k++) ((uint4 *)row)[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
