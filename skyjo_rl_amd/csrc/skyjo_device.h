@@ -1332,9 +1332,6 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
   if (!REGACC)
     for (int k = 0; k < SK_ACC_KINDS * P.L.N; k++) ACC(k) = 0.0;
   STAMP_DECL;
-#ifdef SK_AB_STEP_PRIO  // (A/B builds) the step wavefront ahead of the dealing wavefront it shares its SIMD with
-  __builtin_amdgcn_s_setprio(SK_AB_STEP_PRIO);
-#endif
   // the tile comes in by LDS-DMA as well (non-temporal: it is read once per launch)
   dma_record<true>((const uint8_t *)P.state, (uint32_t)((((size_t)tile * P.L.chunks) * SK_TILE + lane) * 16), lds_tile, P.L.chunks);
   if (P.ov_flags & 1u) sk_publish_deals(P, g);  // (while the tile is on its way)
@@ -1857,15 +1854,6 @@ struct MtChunkStream {
     const uint32_t lm = live ? 0xffffffffu : 0u;  // (a select the compiler cannot turn into a branch around the tempering)
 #pragma unroll
     for (int k = 0; k < 16; k++) R[k] = __builtin_amdgcn_bitop3_b32(R[k], mt_temper3(v[k]), lm, 0xd8);
-#ifdef SK_AB_OWNER_STORES  // (A/B builds) every lane stores its own chunk: no staging through LDS, four times the write requests
-    if (live) {
-      uint4 *pm = (uint4 *)(mt + c);
-#pragma unroll
-      for (int k = 0; k < 4; k++) pm[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
-    }
-    issue();
-    return;
-#endif
     uint8_t *row = stg + lane * SK_STG_STRIDE;
 #pragma unroll
     for (int k = 0; k < 4; k++) ((uint4 *)row)[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
@@ -2330,9 +2318,6 @@ template <int NP>
 __device__ __forceinline__ void deal_body(const SkParams &P, int list_sel, int publish_inline, const int block, const int lane, uint32_t *lds_raw,
                                           const bool report_health = true) {
   TRACE_DECL;
-#ifdef SK_AB_DEAL_PRIO  // (A/B builds) the dealing wavefront ahead of the step wavefront it shares its SIMD with
-  __builtin_amdgcn_s_setprio(SK_AB_DEAL_PRIO);
-#endif
   uint8_t *lp = (uint8_t *)lds_raw + lane * 16;
   const size_t G = (size_t)P.tiles * SK_TILE;
   const int count = (int)P.deal_count[list_sel];
