@@ -65,7 +65,7 @@ def text():
     w("| Quantity | Value |")
     w("|---|---|")
     w(f"| `value` (config 3: 65 536 × 3, MT19937, records) | **{sci(b['value'])} env-steps/s** (`{R}_bench.json`; blocks {sci(b['blocks']['min'])} – {sci(b['blocks']['max'])}; "
-      f"{b['ms_per_iteration'] * 1e3:.3f} µs per lockstep iteration; round 4: 4.29 × 10¹⁰; from box to box ± 2 %: 4.6 – 4.85 seen in the round's A/B runs); target was 10⁷ |")
+      f"{b['ms_per_iteration'] * 1e3:.3f} µs per lockstep iteration; round 4: 4.29 × 10¹⁰; from box to box ± 3 %: 4.6 – 4.9 in the runs of this round - the profiled run of `r5_kernel_stats.csv` was on a 4.7 box); target was 10⁷ |")
     w(f"| `roofline` (`k_cycle<indirect, 3, planar>`, the only kernel of the path) | {th(alg / 1e6)} MB algorithmic (65 536 × (2·238 + {iters}·60)) / "
       f"{th(rf['avg_launch_ms'] * 1e3)} µs (HIP events, last 32 launches) = {rf['achieved'] / 1e3:.2f} TB/s = **{rf['frac']:.3f} of 8 TB/s** — the dealing is INSIDE this time; "
       f"`rocprofv3 --stats`: **{th(avg_us)} µs** average over {calls} launches of a separate, profiled run, {th(kc['last32_avg_us'])} µs"
