@@ -2472,8 +2472,8 @@ __global__ __launch_bounds__(SK_TILE) void k_deal(SkParams P, int list_sel, int 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_cycle: one kernel per dealing cycle - stepping and dealing side by side inside every workgroup (fused rollout, two to
-// four players, indirect observation).
+// k_cycle: one kernel for one to sixteen dealing cycles - stepping and dealing side by side inside every workgroup (fused rollout,
+// two to four players, either observation; PLANAR: the indirect observation's records leave tile-planar, SKYJO_OPT_RECORD_LAYOUT).
 //
 // A workgroup is S step wavefronts + S dealing wavefronts on one CU (S = 4 on a full chip: eight wavefronts, two per SIMD;
 // S = 1 .. 3 for batches of up to 256 .. 768 tiles, every wavefront on a SIMD of its own).  The dealing wavefronts deal for the
