@@ -902,11 +902,7 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
     const int ns = (h.w1 >> 8) & 0xff;
     const int hidden_p = (int)((row_pre.w >> 16) & 0xffu);
     int pile_top = LI(pb + pile_addr(role, nd > 0 ? nd - 1 : 0));
-#ifdef SK_AB_TOPREG
-    const int disc_top = (int)(int8_t)(h.w1 >> 24);  // (H_TOP is the discard pile's top whenever it holds a card: always, in a draw phase)
-#else
     const int disc_top = LI(pb + pile_addr(role ^ 1, ns > 0 ? ns - 1 : 0));
-#endif
     const int disc_below = LI(pb + pile_addr(role ^ 1, ns > 1 ? ns - 2 : 0));
 
     if (hidden_p == 0) {
@@ -1031,12 +1027,8 @@ __device__ __forceinline__ void apply_action(const SkParams &P, uint8_t *lp, uin
   // num_placed[p]++ (skyjo.py:424) as a fire-and-forget add on the dword that holds the u16: no read, no wait
   __hip_atomic_fetch_add((uint32_t *)(lp + LIDX(blk + PB_PLACED)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   const int ms = sum < oms ? sum : oms, mh = hid < omh ? hid : omh;
-#ifdef SK_AB_MIN16
-  LH(H_MINSUM) = (uint16_t)(((uint32_t)(ms < 127 ? ms : 127) & 0xffu) | ((uint32_t)mh << 8));  // (bytes 16, 17: one store)
-#else
   LB(H_MINSUM) = (uint8_t)(int8_t)(ms < 127 ? ms : 127);
   LB(H_MINHID) = (uint8_t)mh;
-#endif
   h.w1 = (h.w1 & 0x00ff00ffu) | ((uint32_t)ns << 8) | (((uint32_t)top & 0xffu) << 24);
   h.w2 = (h.w2 & 0x00ffffffu) | ((uint32_t)SKYJO_HAND_NONE << 24);
   const int np = p + 1 == N ? 0 : p + 1;  // skyjo.py:114-120,142-144
