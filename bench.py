@@ -104,9 +104,9 @@ def launch_shape(B, N, chunk, rng, form, records, direct, layout="row-major"):
 
 
 def pick_layout(eng, asked, indirect):
-    """'tile-planar' wherever the kernel exists (the one-kernel form of the fused rollout, indirect observation) unless row-major is asked for."""
+    """'tile-planar' wherever the kernel exists (the one-kernel form of the fused rollout) unless row-major is asked for."""
     if asked == "auto":
-        return "tile-planar" if (eng.dealing_form() == "one kernel" and indirect) else "row-major"
+        return "tile-planar" if eng.dealing_form() == "one kernel" else "row-major"
     return asked
 
 

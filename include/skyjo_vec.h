@@ -177,8 +177,8 @@ int skyjo_vec_observe(skyjo_vec *h, const int32_t *players, void *records_out, v
 /* Split records into the reference's dense arrays: obs int8[n][D], mask int8[n][26]; any output may be NULL. */
 int skyjo_vec_unpack(skyjo_vec *h, const void *records, int64_t n_records, int8_t *obs, int8_t *mask,
                      uint8_t *agent, uint8_t *phase, uint8_t *done, uint8_t *status, void *stream);
-/* The same for records in the tile-planar layout (SKYJO_OPT_RECORD_LAYOUT = SKYJO_REC_TILE_PLANAR): `n_tiles` blocks of 4 KiB
- * (64 records each) in, dense rows of 64 n_tiles records out - [iters * tiles] blocks of a rollout give rows ordered
+/* The same for records in the tile-planar layout (SKYJO_OPT_RECORD_LAYOUT = SKYJO_REC_TILE_PLANAR): `n_tiles` blocks of 64 records
+ * (64 * record_bytes bytes each) in, dense rows of 64 n_tiles records out - [iters * tiles] blocks of a rollout give rows ordered
  * (iteration, tile, lane), i.e. (iteration, game) with the games of a partial last tile padded to 64. */
 int skyjo_vec_unpack_tiles(skyjo_vec *h, const void *records, int64_t n_tiles, int8_t *obs, int8_t *mask,
                            uint8_t *agent, uint8_t *phase, uint8_t *done, uint8_t *status, void *stream);
@@ -276,13 +276,14 @@ int skyjo_vec_debug_trace(skyjo_vec *h, uint64_t *out_host);
 #define SKYJO_OPT_NO_BANK 5
 /* SKYJO_OPT_RECORD_LAYOUT - how skyjo_vec_rollout lays out records_out (every other call writes row-major records):
  *   SKYJO_REC_ROW_MAJOR    [iters][num_envs][record_bytes] - the default;
- *   SKYJO_REC_TILE_PLANAR  [iters][tiles][4][64][16], tiles = ceil(num_envs / 64): the 64-byte record of game 64 t + l is cut into
- *                          four 16-byte pieces, piece p at byte ((it * tiles + t) * 4 + p) * 1024 + l * 16.  A tile's records of one
- *                          iteration are still one contiguous 4 KiB block, but every store instruction of the step wavefront now
+ *   SKYJO_REC_TILE_PLANAR  [iters][tiles][P][64][16], tiles = ceil(num_envs / 64), P = record_bytes / 16 (4 for the indirect
+ *                          observation; 5 / 6 / 7 for the direct one with 2 / 3 / 4 players): the record of game 64 t + l is cut into
+ *                          16-byte pieces, piece p at byte ((it * tiles + t) * P + p) * 1024 + l * 16.  A tile's records of one
+ *                          iteration are still one contiguous block (P KiB), but every store instruction of the step wavefront now
  *                          writes 1 KiB of it straight from the registers the record was assembled in - no staging through LDS.
  *                          The buffer holds tiles * 64 records per iteration (the slots of a partial last tile beyond num_envs are
- *                          not written).  The one-kernel form (SKYJO_OPT_OVERLAP 3) with the indirect observation only;
- *                          skyjo_vec_unpack_tiles turns such blocks into the reference's dense arrays. */
+ *                          not written).  The one-kernel form (SKYJO_OPT_OVERLAP 3) only; skyjo_vec_unpack_tiles turns such blocks
+ *                          into the reference's dense arrays. */
 #define SKYJO_OPT_RECORD_LAYOUT 6
 #define SKYJO_REC_ROW_MAJOR 0
 #define SKYJO_REC_TILE_PLANAR 1

@@ -379,20 +379,33 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
     // one kernel for the whole dealing cycle: S step + S dealing wavefronts per workgroup (= per CU)
     uint32_t lds_deal = SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE), tag = h->cycle_deal_tag;
     h->cycle_deal_tag = 0;
-    if (h->cycle_no_defer) lds_deal |= 1u << 29;
+    size_t lds_step_region = h->lds_cycle_step, lds_total = h->lds_cycle;
+    bool no_defer = h->cycle_no_defer;
+    if (h->rec_planar && !ind) {
+      // the direct observation's wide records leave from registers in this layout: the staging area shrinks to the rare paths' 4 KiB of
+      // scratch, and where the card chunks of the deferred scoring did not fit beside it (three players on a full chip) they do now
+      const size_t base = h->lds_tile + 4096, with_defer = base + (size_t)h->P.L.N * 1024;
+      no_defer = (size_t)h->cycle_s * (with_defer + lds_deal) + 32 > 160 * 1024;
+      lds_step_region = no_defer ? base : with_defer;
+      lds_total = (size_t)h->cycle_s * (lds_step_region + lds_deal) + 32;
+    }
+    if (no_defer) lds_deal |= 1u << 29;
     if (const char *e = getenv("SKYJO_CYCLE_SPLIT")) lds_deal |= (uint32_t)(atoi(e) & 3) << 30;  // diagnostic: 1 = roles by SIMD parity, 2 = by SIMD pair
     const int S = h->cycle_s;
     dim3 cgrid((h->P.tiles + S - 1) / S), cblock(2 * S * SK_TILE);
 #define LAUNCHC(I, NP, PL)                                                                                                                 \
-  hipExtLaunchKernelGGL((k_cycle<I, NP, PL>), cgrid, cblock, (uint32_t)h->lds_cycle, s, e0, e1, 0, h->P, rec, act_out, iters, policy_seed, \
-                        h->iter, tag, (uint32_t)h->lds_cycle_step, lds_deal, cycle_len)
-    switch (h->P.L.N * 2 + (ind ? 1 : 0) + (ind && h->rec_planar ? 100 : 0)) {
+  hipExtLaunchKernelGGL((k_cycle<I, NP, PL>), cgrid, cblock, (uint32_t)lds_total, s, e0, e1, 0, h->P, rec, act_out, iters, policy_seed, \
+                        h->iter, tag, (uint32_t)lds_step_region, lds_deal, cycle_len)
+    switch (h->P.L.N * 2 + (ind ? 1 : 0) + (h->rec_planar ? 100 : 0)) {
       case 5: LAUNCHC(true, 2, false); break;
       case 7: LAUNCHC(true, 3, false); break;
       case 9: LAUNCHC(true, 4, false); break;
       case 105: LAUNCHC(true, 2, true); break;
       case 107: LAUNCHC(true, 3, true); break;
       case 109: LAUNCHC(true, 4, true); break;
+      case 104: LAUNCHC(false, 2, true); break;
+      case 106: LAUNCHC(false, 3, true); break;
+      case 108: LAUNCHC(false, 4, true); break;
       case 4: LAUNCHC(false, 2, false); break;
       case 6: LAUNCHC(false, 3, false); break;
       default: LAUNCHC(false, 4, false); break;
@@ -628,7 +641,8 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
     if (fits) {
       const void *fn = P.L.indirect ? (cfg->num_players == 2 ? (const void *)k_cycle<true, 2, false> : cfg->num_players == 3 ? (const void *)k_cycle<true, 3, false> : (const void *)k_cycle<true, 4, false>)
                                     : (cfg->num_players == 2 ? (const void *)k_cycle<false, 2, false> : cfg->num_players == 3 ? (const void *)k_cycle<false, 3, false> : (const void *)k_cycle<false, 4, false>);
-      const void *fnp = !P.L.indirect ? nullptr : cfg->num_players == 2 ? (const void *)k_cycle<true, 2, true> : cfg->num_players == 3 ? (const void *)k_cycle<true, 3, true> : (const void *)k_cycle<true, 4, true>;
+      const void *fnp = P.L.indirect ? (cfg->num_players == 2 ? (const void *)k_cycle<true, 2, true> : cfg->num_players == 3 ? (const void *)k_cycle<true, 3, true> : (const void *)k_cycle<true, 4, true>)
+                                     : (cfg->num_players == 2 ? (const void *)k_cycle<false, 2, true> : cfg->num_players == 3 ? (const void *)k_cycle<false, 3, true> : (const void *)k_cycle<false, 4, true>);
       // (the attribute belongs to the function, not to the handle: always the whole CU, so that engines of different batch sizes -
       // different S - can live side by side in one process)
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -931,8 +945,8 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
   hipStream_t s = (hipStream_t)stream;
   uint8_t *rec = (uint8_t *)records_out;
   const bool planar = h->rec_planar;
-  if (planar && rec && !(h->merged && h->P.L.indirect))
-    return fail(SKYJO_E_STATE, "SKYJO_OPT_RECORD_LAYOUT = tile-planar needs the one-kernel dealing form (SKYJO_OPT_OVERLAP 3) and the indirect observation");
+  if (planar && rec && !h->merged)
+    return fail(SKYJO_E_STATE, "SKYJO_OPT_RECORD_LAYOUT = tile-planar needs the one-kernel dealing form (SKYJO_OPT_OVERLAP 3)");
   for (int done = 0; done < iters;) {
     int n = iters - done < kMaxRolloutChunk ? iters - done : kMaxRolloutChunk;
     // a launch ends where the next dealing run is due, so the cadence does not depend on how the caller slices its calls
@@ -1000,7 +1014,6 @@ int skyjo_vec_unpack(skyjo_vec *h, const void *records, int64_t n, int8_t *obs, 
 
 int skyjo_vec_unpack_tiles(skyjo_vec *h, const void *records, int64_t n_tiles, int8_t *obs, int8_t *mask, uint8_t *agent,
                            uint8_t *phase, uint8_t *done, uint8_t *status, void *stream) {
-  if (h && (!h->P.L.indirect || h->P.L.rec_bytes != 64)) return fail(SKYJO_E_STATE, "tile-planar records exist for the indirect observation only");
   return unpack_impl(h, records, n_tiles * SK_TILE, obs, mask, agent, phase, done, status, stream, 1);
 }
 
@@ -1469,8 +1482,8 @@ int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
       return SKYJO_OK;
     case SKYJO_OPT_RECORD_LAYOUT:
       if (value != SKYJO_REC_ROW_MAJOR && value != SKYJO_REC_TILE_PLANAR) return fail(SKYJO_E_INVALID, "SKYJO_OPT_RECORD_LAYOUT takes SKYJO_REC_ROW_MAJOR or SKYJO_REC_TILE_PLANAR");
-      if (value == SKYJO_REC_TILE_PLANAR && !(h->merged_capable && h->P.L.indirect))
-        return fail(SKYJO_E_INVALID, "the tile-planar record layout exists for the one-kernel form of the fused rollout (two to four players, indirect observation)");
+      if (value == SKYJO_REC_TILE_PLANAR && !h->merged_capable)
+        return fail(SKYJO_E_INVALID, "the tile-planar record layout exists for the one-kernel form of the fused rollout (two to four players)");
       h->rec_planar = value == SKYJO_REC_TILE_PLANAR;
       return SKYJO_OK;
     case SKYJO_OPT_DEBUG_SPIN_LOG2:

@@ -1292,7 +1292,7 @@ __device__ __forceinline__ uint32_t sk_next_tag(uint32_t t) {
   t = (t + 1u) & 0x7fffffffu;
   return t ? t : 1u;
 }
-// PLANAR (the fused rollout of k_cycle, indirect observation): the records leave in the tile-planar layout (include/skyjo_vec.h,
+// PLANAR (the fused rollout of k_cycle): the records leave in the tile-planar layout (include/skyjo_vec.h,
 // SKYJO_OPT_RECORD_LAYOUT) - piece p (16 bytes) of lane l's record at  block + p * 1024 + l * 16  of the tile's 4 KiB block - so every
 // store instruction writes 1 KiB contiguously STRAIGHT FROM THE REGISTERS the record was assembled in: no LDS staging, no
 // read-back, no wait between assembling a record and the next iteration.
@@ -1313,7 +1313,10 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
   // iteration's were read back (LDS executes a wavefront's accesses in order).
   uint8_t *stg = (uint8_t *)lds_raw + P.L.chunks * 1024;
   uint8_t *fp = stg + lane * 4;
-  uint8_t *ap = stg + (INDIRECT ? 4096 : SK_TILE * (P.L.rec_bytes + 16)) + lane * 8;
+  // (tile-planar records leave from registers: the staging area then only is the rare paths' 4 KiB of scratch, also for the wide
+  // records of the direct observation)
+  const int stg_bytes = (INDIRECT || PLANAR) ? 4096 : SK_TILE * (P.L.rec_bytes + 16);
+  uint8_t *ap = stg + stg_bytes + lane * 8;
   // deferred scoring (fixed player counts under the on-device policy): one card chunk per player and lane.  The kernels with
   // a compile-time player count keep the per-seat statistics in registers (REGACC: fewer LDS atomics, -2 % for the fused
   // rollout, -8 % for a step with caller actions) - their LDS is tile | staging (| card chunks of the deferred scoring),
@@ -1327,7 +1330,7 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
   double *racc = REGACC ? racc_store : nullptr;
   // (defer_ok false - k_cycle where four step regions WITH the card chunks of the deferred scoring would overflow a CU's LDS, four
   // players / the direct observation on a full chip: games are scored in the iteration they end, the region is tile + staging)
-  uint8_t *pendp = DEFER && defer_ok ? stg + (INDIRECT ? 4096 : SK_TILE * (P.L.rec_bytes + 16)) + (REGACC ? 0 : SK_ACC_KINDS * P.L.N * 512) + lane * 16 : nullptr;
+  uint8_t *pendp = DEFER && defer_ok ? stg + stg_bytes + (REGACC ? 0 : SK_ACC_KINDS * P.L.N * 512) + lane * 16 : nullptr;
   int pend_fin = -1;
   if (!REGACC)
     for (int k = 0; k < SK_ACC_KINDS * P.L.N; k++) ACC(k) = 0.0;
@@ -1441,6 +1444,17 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
 #pragma unroll
             for (int p = 0; p < 4; p++) *(uint4 *)(stg + lane * 64 + ((p + (lane >> 1)) & 3) * 16) = rr[p];
           }
+        } else if (PLANAR) {  // direct observation, tile-planar: rec_bytes / 16 pieces (5 / 6 / 7), assembled in registers
+          constexpr int PIECES = NP > 0 ? (((19 + 12 * NP + 3) & ~3) + 32 + 15) / 16 : 1;
+          uint32_t wbuf[4 * PIECES];
+#pragma unroll
+          for (int k = 0; k < 4 * PIECES; k++) wbuf[k] = 0u;
+          emit_record<INDIRECT>(P, lp, h, ob, a, (uint8_t *)wbuf, nullptr, &rec_a, rec_b);
+          typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+          uint8_t *blk = rec_out + ((size_t)it * P.tiles + (size_t)tile) * (SK_TILE * 16 * PIECES) + lane * 16;
+#pragma unroll
+          for (int p = 0; p < PIECES; p++)
+            __builtin_nontemporal_store((u32x4_t){wbuf[4 * p], wbuf[4 * p + 1], wbuf[4 * p + 2], wbuf[4 * p + 3]}, (u32x4_t *)(blk + p * 1024));
         } else {  // direct observation: rec_bytes = 80 / 96 / 112 ...; staged record-major with a stride that spreads the banks
           emit_record<INDIRECT>(P, lp, h, ob, a, stg + lane * sk_stage_stride(P.L.rec_bytes), nullptr, &rec_a, rec_b);
         }
@@ -1464,7 +1478,7 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
         }
       }
     }
-    if (!INDIRECT && rec_out) {  // same idea for the wider records of the direct observation: rec_bytes / 16 pieces each
+    if (!INDIRECT && !PLANAR && rec_out) {  // same idea for the wider records of the direct observation: rec_bytes / 16 pieces each
       typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
       const int pieces = P.L.rec_bytes >> 4, stride = sk_stage_stride(P.L.rec_bytes);
       uint8_t *blk = rec_out + ((size_t)it * P.B + (size_t)tile * SK_TILE) * (size_t)P.L.rec_bytes;
@@ -2668,9 +2682,9 @@ __global__ void k_episode_ends(SkParams P, const uint8_t *rec, double *rew_out, 
 }
 
 // records -> the reference's dense arrays (obs int8[n][D], mask int8[n][26], ...).  `planar`: the records lie tile-planar
-// (SKYJO_REC_TILE_PLANAR: byte k of record r at  (r / 64) * 4096 + (k / 16) * 1024 + (r % 64) * 16 + k % 16; 64-byte records).
+// (SKYJO_REC_TILE_PLANAR: byte k of record r at  (r / 64) * 64 * rec_bytes + (k / 16) * 1024 + (r % 64) * 16 + k % 16).
 __device__ __forceinline__ const uint8_t *sk_rec_byte(const uint8_t *rec, long long r, int k, int rec_bytes, int planar) {
-  return planar ? rec + (r >> 6) * 4096 + (long long)(k >> 4) * 1024 + (r & 63) * 16 + (k & 15) : rec + r * rec_bytes + k;
+  return planar ? rec + (r >> 6) * (64LL * rec_bytes) + (long long)(k >> 4) * 1024 + (r & 63) * 16 + (k & 15) : rec + r * rec_bytes + k;
 }
 __global__ void k_unpack(SkLayout L, const uint8_t *rec, long long n, int8_t *obs, int8_t *mask, uint8_t *agent,
                          uint8_t *phase, uint8_t *done, uint8_t *status, int planar) {

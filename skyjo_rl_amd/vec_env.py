@@ -120,23 +120,22 @@ class SkyjoVecEnv:
 
     def set_record_layout(self, layout):
         """'row-major' (default) or 'tile-planar' (include/skyjo_vec.h: SKYJO_OPT_RECORD_LAYOUT): how ``rollout`` lays out its
-        records.  Tile-planar records come as ``new_planar_records(iters)`` = uint8 [iters, tiles, 4, 64, 16]."""
+        records.  Tile-planar records come as ``new_planar_records(iters)`` = uint8 [iters, tiles, record_bytes / 16, 64, 16]."""
         _lib.check(self._L.skyjo_vec_set_option(self._h, 6, {"row-major": 0, "tile-planar": 1}[layout]))
         self.record_layout = layout
 
     def new_planar_records(self, iters):
-        assert self.record_bytes == 64
-        return self._torch().empty((iters, self.tiles, 4, 64, 16), dtype=self._torch().uint8, device=self._dev())
+        return self._torch().empty((iters, self.tiles, self.record_bytes // 16, 64, 16), dtype=self._torch().uint8, device=self._dev())
 
     def rows_from_planar(self, records):
-        """Row-major copy [iters, num_envs, 64] of tile-planar records (``split`` / ``unpack`` take it from there)."""
+        """Row-major copy [iters, num_envs, record_bytes] of tile-planar records (``split`` / ``unpack`` take it from there)."""
         it, t = records.shape[0], records.shape[1]
-        return records.permute(0, 1, 3, 2, 4).reshape(it, t * 64, 64)[:, :self.num_envs]
+        return records.permute(0, 1, 3, 2, 4).reshape(it, t * 64, self.record_bytes)[:, :self.num_envs]
 
     def unpack_tiles(self, records):
         """Dense obs int8[n, D], mask int8[n, 26] straight from tile-planar blocks (n = 64 x number of blocks)."""
         torch = self._torch()
-        nt = records.numel() // 4096
+        nt = records.numel() // (64 * self.record_bytes)
         obs = torch.empty((nt * 64, self.obs_dim), dtype=torch.int8, device=self._dev())
         mask = torch.empty((nt * 64, 26), dtype=torch.int8, device=self._dev())
         _lib.check(self._L.skyjo_vec_unpack_tiles(self._h, C.c_void_p(records.data_ptr()), nt, C.c_void_p(obs.data_ptr()),
