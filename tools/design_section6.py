@@ -85,7 +85,7 @@ def text():
     w(f"| `other_configs` (same run; k_cycle at sixteen cycles per launch, planar records unless said) | cfg2 4 096 × 2: **{sci(o('cfg2_4096x2'))}** (round 4: 3.24) · cfg4 shard 32 768 × 3 "
       f"(`game_id0 = 3·32 768`): **{sci(o('cfg4_shard_32768x3'))}** (2.48; × 8 GPUs = {sci(8 * o('cfg4_shard_32768x3'), 1)} is a PROJECTION from one shard, not a measurement: §7) · Philox: "
       f"**{sci(o('philox_65536x3'))}** (4.84; {sci(o('philox_131072x3'))} at 131 072 games, two rounds of workgroups) · row-major records (the ABI's default layout): **{sci(o('row_major_records_65536x3'))}** · "
-      f"direct observation: **{sci(o('direct_obs_65536x3'))}** (3.05) · cfg5 65 536 × 4 with policy + value net: {sci(o('cfg5_65536x4_model_bf16'))} (bf16), {sci(o('cfg5_65536x4_model_fp32'))} "
+      f"direct observation (tile-planar since round 5): **{sci(o('direct_obs_65536x3'))}** (3.05) · cfg5 65 536 × 4 with policy + value net: {sci(o('cfg5_65536x4_model_bf16'))} (bf16), {sci(o('cfg5_65536x4_model_fp32'))} "
       "(float32-grade) — unchanged, two launches per lockstep iteration: §8 |")
     w("| config 1 (`tools/bench_cfg1.py`, `profiles/r4_cfg1.json`; not re-measured in round 5) | ONE game from Python through the reference's own loops: `env(**DEFAULT_CONFIG)` 32 – 35 k steps/s, `SkyjoGame` core loop 37 – 41 k; "
       "the reference's Python: 6.9 k / 8.3 k.  Floor: one native host-style call is 13 – 14 µs, the rest is Python |")
