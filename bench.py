@@ -68,14 +68,38 @@ TRAFFIC_PROFILE = os.path.join("profiles", "r5_hbm_traffic.json")  # rocprofv3 P
 KERNEL_SOURCES = ("skyjo_rl_amd/csrc/skyjo_device.h", "skyjo_rl_amd/csrc/skyjo_capi.hip", "skyjo_rl_amd/csrc/skyjo_layout.h")
 
 
+def _code_only(text):
+    """C++ source without comments and with runs of white space collapsed (string / character literals are kept as they are)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":  # a literal: copy through to its closing quote
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def kernel_source_sha256():
-    """sha256 over the kernel sources: tools/collect_profiles.py stores it with the PMC traffic it digests, and the traffic
-    figure is only reported for the sources it was measured on."""
+    """sha256 over the kernel sources' CODE (comments and white space do not count): tools/collect_profiles.py stores it with the
+    PMC traffic it digests, and the traffic figure is only reported for the code it was measured on."""
     import hashlib
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(ROOT, f), "r", errors="replace") as fh:
+            h.update(_code_only(fh.read()).encode())
     return h.hexdigest()
 
 

@@ -62,7 +62,7 @@ struct SkParams {
   double score_penalty, mean_reward, reward_refunded, illegal_reward;
   uint64_t game_id0;
   uint4 *state;             // [tiles][chunks][64] live games
-  uint4 *spare;             // [SK_BANK][tiles][chunks][64] the game's bank of pre-dealt next episodes
+  uint4 *spare;             // [SK_BANK][tiles * 64][chunks] the game's bank of pre-dealt next episodes, GAME-major (bank_rec16)
   uint8_t *spare_ready;     // [SK_BANK][tiles*64]; the ready slots of a game are head, head+1, ... (mod SK_BANK)
   uint8_t *bank_head;       // [tiles*64] slot that is taken next (mirrored in the record header, H_BANK)
   uint8_t *busy;            // [tiles*64] 0, or 1 + slot while the dealing kernel owns the game's stream and that slot

@@ -57,3 +57,14 @@ def test_traffic_is_tied_to_the_kernel_sources_it_was_measured_on(tmp_path, monk
     assert t[0] is None and t[1] is None and "other kernel sources" in t[2]
     prof.write_text(json.dumps({"kernel_source_sha256": sha, "shape": shape, "k_step_bytes_per_launch": 5, "k_deal_fabric": {"read_bytes": 3, "write_bytes": 4}}))
     assert bench.committed_traffic(shape)[:2] == (5, 7)
+
+
+def test_the_source_hash_ignores_comments_and_white_space(tmp_path, monkeypatch):
+    """A comment fix in a kernel source must not orphan the committed PMC digest; a code change must."""
+    import bench
+
+    a = bench._code_only('int f(int x) {  // add one\n  return x + 1; /* really */ }\n')
+    b = bench._code_only('int f(int x) {\n\n return x + 1;   }')
+    c = bench._code_only('int f(int x) { return x + 2; }')
+    assert a == b and a != c
+    assert bench._code_only('const char *s = "// not a comment"; // one') == 'const char *s = "// not a comment";'
