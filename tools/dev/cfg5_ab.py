@@ -11,6 +11,7 @@ for prec in ("bf16", "fp32"):
 print(json.dumps(out))
 '''
 for v in (sys.argv[1:] or [""]):
+    v = v.replace("LIB=", "SKYJO_LIB=")
     env = dict(os.environ)
     for kv in v.split():
         k, val = kv.split("=", 1)
