@@ -1,5 +1,5 @@
 """One-off soak: the fused rollout at the headline size, eight dealing cycles per launch, every record of every iteration against
-the oracle over many episodes per game.   python tools/dev/soak_parity.py [launches] [players] [games]"""
+the oracle over many episodes per game.   python tools/dev/soak_parity.py [launches] [players] [games] [row-major|tile-planar]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -12,12 +12,15 @@ cfg = dict(num_players=N, score_penalty=2.0, observe_other_player_indirect=True,
 eng = SkyjoVecEnv(B, **cfg); ora = so.OracleVec(num_envs=B, **cfg)
 eng.seed(None, 123); ora.seed(None, 123)
 K = eng.deal_interval() * 8
-rec = eng.new_records(K)
+PLANAR = (sys.argv[4] if len(sys.argv) > 4 else "tile-planar") == "tile-planar"
+if PLANAR:
+    eng.set_record_layout("tile-planar")
+rec = eng.new_planar_records(K) if PLANAR else eng.new_records(K)
 t0 = time.time()
 for r in range(L):
     eng.rollout(K, policy_seed=77, records=rec)
     oact, obs, mask, meta, eplen = ora.rollout(K, 77, threads=min(32, os.cpu_count() or 1), record_obs=True)
-    v = eng.split(rec)
+    v = eng.split(eng.rows_from_planar(rec) if PLANAR else rec)
     for name, a, b in (("action", v.action, oact.astype(np.int8)), ("obs", v.observations, obs), ("mask", v.action_mask, mask), ("agent", v.agent, meta[..., 0]),
                        ("phase", v.phase, meta[..., 1]), ("done", v.done, meta[..., 2]), ("status", v.status, meta[..., 3])):
         assert np.array_equal(a.cpu().numpy(), b), (name, r)
