@@ -535,7 +535,8 @@ def main():
                               "refunded_per_episode": float(tot["sum_refunded"].sum() / max(episodes, 1.0))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": (f"k_cycle<indirect,{N}> (step + dealing wavefronts of one dealing cycle)" if eng.dealing_form() == "one kernel" else
+                         "kernel": (f"k_cycle<{'direct' if args.direct_obs else 'indirect'},{N},{'planar' if planar else 'row-major'}> (step + dealing wavefronts of "
+                                    f"{CHUNK // max(eng.deal_interval(), 1)} dealing cycles)" if eng.dealing_form() == "one kernel" else
                                     f"k_step<{'indirect' if not args.direct_obs else 'direct'},policy,{N if N in (2, 3, 4) else 0}>"), "avg_launch_ms": avg_ms,
                          "launches_timed": full, "algorithmic_bytes_per_launch": alg, "launch_shape": shape,
                          "deal_kernel_avg_ms": prof["deal_ms"] / max(prof["deal_launches"], 1)},

@@ -68,3 +68,15 @@ def test_bench_two_ranks_on_one_card_rehearsal_and_refusal():
                       env={"SKYJO_BENCH_SHARED_GPU": "1"}))
     assert ds["scaling"] == "strong" and ds["config"]["games_per_gpu"] == 32768 and ds["config"]["games_total"] == 65536
     assert ds["config"]["scaling_mode"].startswith("strong")
+
+
+def test_bench_flags_for_the_other_layout_and_observation():
+    """`--record-layout row-major` (the ABI's default layout) and `--direct-obs` (wider records, tile-planar by default) run the same
+    timed loop; the line says which layout it measured, and the PMC traffic figure is only reported for the shape it was taken on."""
+    common = ("--steps", "2", "--warmup", "1", "--blocks", "1", "--no-cpu-baseline", "--no-other-configs")
+    d = _line(_bench("--record-layout", "row-major", *common))
+    assert d["config"]["record_layout"] == "row-major" and d["roofline"]["launch_shape"]["record_layout"] == "row-major"
+    assert d["roofline"]["traffic"] is None and "launch shape" in d["roofline"]["traffic_source"] and d["value"] > 1e9
+    d = _line(_bench("--direct-obs", *common))
+    assert d["config"]["record_layout"] == "tile-planar" and d["roofline"]["launch_shape"]["direct_obs"] is True and d["value"] > 1e9
+    assert "direct" in d["roofline"]["kernel"]
