@@ -87,8 +87,10 @@ def text():
       f"**{sci(o('philox_65536x3'))}** (4.84; {sci(o('philox_131072x3'))} at 131 072 games, two rounds of workgroups) · row-major records (the ABI's default layout): **{sci(o('row_major_records_65536x3'))}** · "
       f"direct observation (tile-planar since round 5): **{sci(o('direct_obs_65536x3'))}** (3.05) · cfg5 65 536 × 4 with policy + value net: {sci(o('cfg5_65536x4_model_bf16'))} (bf16), {sci(o('cfg5_65536x4_model_fp32'))} "
       "(float32-grade) — unchanged, two launches per lockstep iteration: §8 |")
-    w("| config 1 (`tools/bench_cfg1.py`, `profiles/r4_cfg1.json`; not re-measured in round 5) | ONE game from Python through the reference's own loops: `env(**DEFAULT_CONFIG)` 32 – 35 k steps/s, `SkyjoGame` core loop 37 – 41 k; "
-      "the reference's Python: 6.9 k / 8.3 k.  Floor: one native host-style call is 13 – 14 µs, the rest is Python |")
+    c1 = json.load(open(P("cfg1.json")))
+    w(f"| config 1 (`tools/bench_cfg1.py`, `profiles/{R}_cfg1.json`) | ONE game from Python through the reference's own loops: `env(**DEFAULT_CONFIG)` "
+      f"{c1['env_steps_per_s'] / 1e3:.1f} k steps/s ({c1['env_us_per_step']:.1f} µs per step), `SkyjoGame` core loop {c1['core_steps_per_s'] / 1e3:.1f} k ({c1['core_us_per_step']:.1f} µs); "
+      f"the reference's Python: 6.9 k / 8.3 k.  Floor: one native host-style call is {c1['native_call_floor_us']:.1f} µs, the rest is Python |")
     w("")
     return "\n".join(lines)
 
