@@ -71,12 +71,15 @@ CASES = [
     ("cfg2_sixteen_cycles_tile_planar", 4096, 2, True, 0, 0, 2, -16, 0),                  # (other_configs.cfg2_4096x2: 896 iterations)
     ("philox_sixteen_cycles_tile_planar", 65536, 3, True, 1, 0, 1, -16, 0),               # (other_configs.philox_65536x3)
     ("partial_tile_tile_planar", 40010, 2, True, 0, 0, 2, -4, 0),
+    # twice the chip's share of tiles: 512 workgroups of eight wavefronts in two rounds, the cycle ends inside every one of them
+    ("philox_131072_sixteen_cycles_tile_planar", 131072, 3, True, 1, 0, 1, -16, 0),      # (other_configs.philox_131072x3)
+    ("mt_131072_eight_cycles_tile_planar", 131072, 3, True, 0, 0, 1, -8, 0),
     ("direct_obs_sixteen_cycles_tile_planar", 65536, 3, False, 0, 0, 1, -16, 0),   # (other_configs.direct_obs_65536x3 since round 5)
 ]
 ONE_KERNEL = {"cfg3_headline", "cfg2", "cfg4_shard", "philox", "cfg5_shape_N4_one_kernel_S3", "cfg3_four_cycles_per_launch",
               "cfg2_eight_cycles_per_launch", "cfg3_eight_cycles", "cfg3_sixteen_cycles", "cfg4_shard_eight_cycles_S2", "N4_S3_four_cycles",
               "partial_wg_S3_multi_cycle", "partial_wg_S2_multi_cycle", "surplus_wavefronts_S4_7_tiles", "direct_obs_eight_cycles",
-              "philox_eight_cycles", "cfg3_sixteen_cycles_tile_planar", "cfg4_shard_sixteen_cycles_tile_planar", "cfg2_sixteen_cycles_tile_planar", "philox_sixteen_cycles_tile_planar", "partial_tile_tile_planar", "direct_obs_sixteen_cycles_tile_planar"}
+              "philox_eight_cycles", "cfg3_sixteen_cycles_tile_planar", "cfg4_shard_sixteen_cycles_tile_planar", "cfg2_sixteen_cycles_tile_planar", "philox_sixteen_cycles_tile_planar", "partial_tile_tile_planar", "philox_131072_sixteen_cycles_tile_planar", "mt_131072_eight_cycles_tile_planar", "direct_obs_sixteen_cycles_tile_planar"}
 SLICE = 64  # iterations the oracle records at a time
 
 
