@@ -452,24 +452,19 @@ int fetch_record(skyjo_vec *h, const uint4 *base, int game, std::vector<uint8_t>
   return SKYJO_OK;
 }
 
-// One launch of the policy net (nets == 2: policy and value branch over the same records, grid.y = 2) in the net's precision.
+// One launch of the policy net (nets == 2: policy and value branch over the same records, grid.y = 2) in the net's precision
+// (the kernels live in skyjo_policy.hip).  `planar`: the records lie tile-planar (SKYJO_REC_TILE_PLANAR).
 // `prof`: the engine whose kernel timing (skyjo_vec_profile, slot 4) collects this launch, or null.
 int launch_mlp(const skyjo_vec_mlp *ma, const skyjo_vec_mlp *mb, int nets, const uint8_t *rec, int rec_bytes, int obs_dim, int64_t n, float *out_a,
-               const SkMlpDraw &draw, float *out_b, hipStream_t s, skyjo_vec *prof = nullptr) {
-  const SkMlpDev &a = ma->net, &b = mb->net;
-  const dim3 grid((unsigned)((n + 32 * SKP_GT * SKP_WG - 1) / (32 * SKP_GT * SKP_WG)), (unsigned)nets), block(64 * SKP_WG);
+               const SkMlpDraw &draw, float *out_b, hipStream_t s, skyjo_vec *prof = nullptr, int planar = 0) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof) {
     int rc = prof_events(prof, 4, &e0, &e1);
     if (rc) return rc;
   }
-  if (a.split) {
-    static_assert(SKP_GT == 1, "the float32-grade kernel handles one tile of 32 games per wavefront");
-    hipExtLaunchKernelGGL(k_mlp_forward_split, grid, block, 0, s, e0, e1, 0, a, rec, rec_bytes, obs_dim, (long long)n, out_a, draw, b, out_b);
-  } else {
-    hipExtLaunchKernelGGL(k_mlp_forward, grid, block, 0, s, e0, e1, 0, a, rec, rec_bytes, obs_dim, (long long)n, out_a, draw, b, out_b);
-  }
-  HIPCHK(hipGetLastError());
+  SkMlpRecords r;
+  r.base = rec, r.rec_bytes = rec_bytes, r.obs_dim = obs_dim, r.planar = planar, r.n = (long long)n;
+  HIPCHK((hipError_t)sk_launch_mlp(ma->net, mb->net, nets, r, out_a, draw, out_b, s, e0, e1));
   return SKYJO_OK;
 }
 
@@ -1057,30 +1052,31 @@ int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, in
     return bf16(f - fh);
   };
   const bool split = precision == SKYJO_MLP_FP32;
+  // The two hidden layers are stored times 2 / ln 2 (weights AND biases, before the rounding to bf16 / the split into two bf16): their
+  // accumulators are then the exponent of tanh(x) = 1 - 2 / (2^(x 2 / ln 2) + 1) as they stand - no multiply per activation (skyjo_policy.hip)
   auto acc_k = [](int ks, int hh, int j) { return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * hh + (j & 3); };
   const int H = SKP_HIDDEN;
   const size_t e1 = (size_t)8 * 2 * 64 * 8, e2 = (size_t)8 * 16 * 64 * 8, e3 = (size_t)16 * 64 * 8;
   std::vector<uint16_t> f1(e1), f2(e2), f3(e3), g1(split ? e1 : 0), g2(split ? e2 : 0), g3(split ? e3 : 0);
-  std::vector<float> c2((size_t)8 * 64 * 16), c3((size_t)64 * 16);
+  std::vector<float> c2((size_t)H), c3((size_t)64 * 16);
   for (int u = 0; u < 8; u++)
     for (int l = 0; l < 64; l++) {
       const int m = 32 * u + (l & 31), hh = l >> 5;
       for (int s = 0; s < 2; s++)
         for (int j = 0; j < 8; j++) {
           const int k = 16 * s + 8 * hh + j;  // natural order: the kernel builds this operand from the record itself
-          const float v = k < obs_dim ? w1[(size_t)m * obs_dim + k] : (k == SKP_IN - 1 ? b1[m] : 0.f);
+          const float v = SKP_SCALE * (k < obs_dim ? w1[(size_t)m * obs_dim + k] : (k == SKP_IN - 1 ? b1[m] : 0.f));
           const size_t at = (((size_t)u * 2 + s) * 64 + l) * 8 + j;
           f1[at] = bf16(v);
           if (split) g1[at] = bf16_lo(v);
         }
       for (int ks = 0; ks < 16; ks++)
         for (int j = 0; j < 8; j++) {
-          const float v = w2[(size_t)m * H + acc_k(ks, hh, j)];
+          const float v = SKP_SCALE * w2[(size_t)m * H + acc_k(ks, hh, j)];
           const size_t at = (((size_t)u * 16 + ks) * 64 + l) * 8 + j;
           f2[at] = bf16(v);
           if (split) g2[at] = bf16_lo(v);
         }
-      for (int r = 0; r < 16; r++) c2[((size_t)u * 64 + l) * 16 + r] = b2[32 * u + (r & 3) + 8 * (r >> 2) + 4 * hh];
     }
   for (int l = 0; l < 64; l++) {
     const int m = l & 31, hh = l >> 5;
@@ -1096,6 +1092,7 @@ int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, in
       c3[(size_t)l * 16 + r] = row < out_dim ? b3[row] : 0.f;
     }
   }
+  for (int u = 0; u < H; u++) c2[u] = SKP_SCALE * b2[u];  // (enters the activation's first multiply-add: skyjo_policy.hip)
   skyjo_vec_mlp *m = new skyjo_vec_mlp();
   m->device_id = device_id, m->obs_dim = obs_dim;
   struct Piece { const void *src; size_t bytes; };

@@ -1,0 +1,686 @@
+// skyjo_policy.hip - config 5 caller: the fully connected net of the action-mask policy model
+// (rlskyjo/models/action_mask_model.py:41-52 builds RLlib's TorchFC: obs -> 256 tanh -> 256 tanh -> outputs) as gfx950
+// kernels on the matrix cores, reading the observation bytes straight out of the engine's records (row-major or
+// tile-planar).  A translation unit of its own (skyjo_policy.h says why).
+//
+// Orientation: everything is computed transposed, H_next^T = W^T * H^T, with the 32 games of a wavefront on the lanes
+// (MFMA column index) and the hidden units on the accumulator registers (row index).  A 32x32 accumulator tile of
+// v_mfma_f32_32x32x16_bf16 can then be fed to the next layer as the B operand without any lane movement or LDS: its
+// registers 8s .. 8s+7, packed to bf16, ARE the fragment of k-step s - in a permuted k order (element j of lane half h
+// is row 16s + 8(j>>2) + 4h + (j&3) of the tile), which the weights follow: they are packed on the host, once, into
+// exactly the per-lane fragments the kernel loads (one 16-byte load per lane and MFMA).
+// Lane maps (gfx950): A[row l&31][k = 8(l>>5)+j], B[k = 8(l>>5)+j][col l&31], C[row (r&3)+8(r>>2)+4(l>>5)][col l&31].
+//
+// Round 6: what the counters said about the round-2 kernels (profiles/r6_cfg5_pmc.json: the matrix pipe busy 27 % / 41 % of the
+// time, the vector ALU 51 % / 37 %, both at once 15 % / 6 %) is that a wavefront did its MFMAs and its activations in turn,
+// and that the workgroup's barriers kept the two wavefronts of a SIMD in the same phase - the two pipes took turns.  Here every
+// wavefront runs a software pipeline of its own: the 16 (48) MFMAs of output tile u + 1 are issued between the activations of
+// tile u (one `tanh` per MFMA gap: v_fma, v_exp, v_add, v_rcp, v_fma + half a v_cvt_pk = 30 issue cycles against the MFMA's 32),
+// layer 3 rides behind (two MFMAs per tile) and layer 2's first chain runs inside layer 1's activations.  The weights of the
+// 256 x 256 layer arrive by LDS-DMA (no registers, no LDS-write instructions) behind the first layer; a workgroup keeps them for
+// `passes` batches of 256 games, so that a 65 536-game launch is ONE round of 256 workgroups.
+#include <hip/hip_ext.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "skyjo_draw.h"
+#include "skyjo_policy.h"
+
+typedef __bf16 skp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float skp_f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t skp_u32x4 __attribute__((ext_vector_type(4)));
+#define SKP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define SKP_LDS32(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(p))
+
+__device__ __forceinline__ skp_bf16x8 skp_frag(const uint4 *p) {
+  const uint4 q = *p;
+  skp_bf16x8 r;
+  __builtin_memcpy(&r, &q, 16);
+  return r;
+}
+__device__ __forceinline__ skp_f32x16 skp_zero() {
+  skp_f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; r++) z[r] = 0.f;
+  return z;
+}
+
+// tanh(x) = 1 - 2 / (2^(x * 2 / ln 2) + 1): the exponential and the reciprocal are the hardware's approximations (v_exp_f32,
+// v_rcp_f32: 1 ulp - 2e-7 absolute on a value in [-1, 1]); an IEEE division made the activation 13 instructions per value.
+// The factor 2 / ln 2 is in the packed weights and biases of the two hidden layers (skyjo_vec_mlp_create), so an accumulator is the
+// exponent as it stands.  2^y = inf for large x -> 1, 0 -> -1.  Plain (unpacked) float32 instructions on purpose: beside MFMAs a
+// v_pk_*_f32 costs more than the two instructions it replaces (MI355X_MICROARCH.md, per-instruction constants).
+
+// the 16-byte piece p of game g's record
+__device__ __forceinline__ const uint4 *skp_piece(const SkMlpRecords &R, long long g, int p) {
+  const uint8_t *b = R.planar ? R.base + (g >> 6) * (64LL * R.rec_bytes) + (long long)p * 1024 + (g & 63) * 16
+                              : R.base + g * R.rec_bytes + (long long)p * 16;
+  return (const uint4 *)b;
+}
+
+// the first 32 bytes of game g's record (zeros beyond the last game)
+__device__ __forceinline__ void skp_record_load(const SkMlpRecords &R, long long g, uint32_t (&ob)[8]) {
+  uint4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+  if (g < R.n) a = *skp_piece(R, g, 0), b = *skp_piece(R, g, 1);
+  ob[0] = a.x, ob[1] = a.y, ob[2] = a.z, ob[3] = a.w, ob[4] = b.x, ob[5] = b.y, ob[6] = b.z, ob[7] = b.w;
+}
+// input fragments: features 16s + 8h .. 16s + 8h + 7 of this lane's game, int8 -> bf16 (exact); feature 31 is the constant 1
+// (obs_dim <= 31: byte 31 of a record is never an observation).  Bytes from obs_dim on are cleared word-wise with masks that
+// depend on obs_dim alone (eight scalar registers; a comparison per feature kept 32 scalar conditions alive through the kernel).
+__device__ __forceinline__ void skp_inputs(const SkMlpRecords &R, const uint32_t (&obr)[8], int h, skp_bf16x8 x[2]) {
+  uint32_t ob[8];
+#pragma unroll
+  for (int w = 0; w < 8; w++) {
+    const int left = R.obs_dim - 4 * w;  // observation bytes in this word
+    const uint32_t m = left >= 4 ? 0xffffffffu : left <= 0 ? 0u : (1u << (8 * left)) - 1u;
+    ob[w] = obr[w] & m;
+  }
+  ob[7] = (ob[7] & 0x00ffffffu) | 0x01000000u;
+#pragma unroll
+  for (int s = 0; s < 2; s++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k0 = 16 * s + j, k1 = 16 * s + 8 + j;  // the feature index 16s + 8h + j for h = 0 / h = 1
+      const float v0 = (float)(int8_t)(ob[k0 >> 2] >> ((k0 & 3) * 8)), v1 = (float)(int8_t)(ob[k1 >> 2] >> ((k1 & 3) * 8));
+      x[s][j] = (__bf16)(h ? v1 : v0);
+    }
+}
+
+// What follows the last layer, for the 32 games of a wavefront: the outputs go to memory (out: float32 [n][out_dim], may be
+// null) and - policy branch - the masked categorical draw is made on the logits in registers (sk_draw_action).
+__device__ __forceinline__ void skp_finish(const skp_f32x16 &acc, const int lane, const long long g, const SkMlpRecords &R, const int out_dim,
+                                           float *out, const SkMlpDraw &draw) {
+  const int h = lane >> 5;
+  if (out && g < R.n) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < out_dim) out[g * out_dim + row] = acc[r];
+    }
+  }
+  if (draw.enable) {
+    // a game's 32 outputs sit in two lanes (this one and lane ^ 32: rows 4h .. 4h+3 of every block of 8): swap halves
+    float full[32];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float other = __shfl_xor(acc[r], 32, 64);
+      const int blk8 = r >> 2, i4 = r & 3;
+      full[8 * blk8 + i4] = h ? other : acc[r];      // rows 0..3 of the block belong to the h = 0 lane
+      full[8 * blk8 + 4 + i4] = h ? acc[r] : other;  // rows 4..7 to the h = 1 lane
+    }
+    if (h == 0 && g < R.n) {
+      uint32_t mw[7];
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        const int off = draw.mask_offset + 4 * k;  // (the mask starts on a 4-byte boundary: a word never straddles two pieces)
+        mw[k] = *(const uint32_t *)((const uint8_t *)skp_piece(R, g, off >> 4) + (off & 15));
+      }
+      float lp = 0.f;
+      draw.actions[g] = sk_draw_action(full, mw, draw.no_masking, draw.seed, draw.ticket, draw.game_id0 + (uint64_t)g,
+                                       draw.logp ? &lp : nullptr, nullptr);
+      if (draw.logp) draw.logp[g] = lp;
+    }
+  }
+}
+
+// Diagnostic build (-DSKP_STAMPS, tools/dev/policy_stamps.py): s_memtime at the phase boundaries of every wavefront, into a buffer
+// of its own that nothing else reads.  The shipped build has none.
+#ifdef SKP_STAMPS
+#define SKP_NSTAMP 32
+__device__ unsigned long long skp_stamp_buf[4096 * SKP_NSTAMP];
+#define SKP_STAMP(k) if (gridDim.y == 2) skp_stamp_buf[(size_t)skp_wave_id * SKP_NSTAMP + (k)] = __builtin_amdgcn_s_memtime()  // (two-net launches only)
+#define SKP_RSTAMP(k) if (gridDim.y == 2) skp_stamp_buf[(size_t)skp_wave_id * SKP_NSTAMP + (k)] = __builtin_amdgcn_s_memrealtime()
+#define SKP_STAMP_DECL const int skp_wave_id = (blockIdx.y * gridDim.x + blockIdx.x) * SKP_WG + (threadIdx.x >> 6)
+extern "C" int skyjo_debug_policy_stamps(unsigned long long *out, int n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(skp_stamp_buf), (size_t)n_words * 8);
+}
+#else
+#define SKP_STAMP(k)
+#define SKP_RSTAMP(k)
+#define SKP_STAMP_DECL
+#endif
+
+// Everything a launch needs, as ONE kernel argument: net[1] / out[1] belong to the second branch (blockIdx.y == 1: no draw).
+struct SkMlpArgs {
+  SkMlpDev net[2];
+  float *out[2];
+  SkMlpRecords R;
+  SkMlpDraw draw;
+  int passes;
+};
+
+// LDS-DMA of 4 KB: four global_load_lds_dwordx4, each 64 lanes x 16 bytes, memory  base + voff + k * 1024  ->  LDS  lds + k * 1024
+// + lane * 16  (the immediate offset applies to both sides; M0 holds the LDS base and is restored).
+__device__ __forceinline__ void skp_dma4k(const uint8_t *base, uint32_t voff, uint32_t lds) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(base), "s"(lds)
+               : "memory");
+}
+__device__ __forceinline__ void skp_dma2k(const uint8_t *base, uint32_t voff, uint32_t lds) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(base), "s"(lds)
+               : "memory");
+}
+__device__ __forceinline__ void skp_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Two activated values -> one register of a bf16 fragment (v_cvt_pk_bf16_f32)
+typedef __bf16 skp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float skp_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t skp_pk(float a, float b) {
+  const skp_bf16x2 p = __builtin_convertvector((skp_f32x2){a, b}, skp_bf16x2);
+  uint32_t r;
+  __builtin_memcpy(&r, &p, 4);
+  return r;
+}
+__device__ __forceinline__ skp_bf16x8 skp_frag4(const uint32_t (&w)[4]) {
+  skp_bf16x8 r;
+  __builtin_memcpy(&r, w, 16);
+  return r;
+}
+
+// The activation of one accumulator tile as a three-stage software pipeline over "gaps" (one gap = the issue slots between two
+// MFMAs): gap i starts value i (multiply-add with scale and bias, v_exp_f32), continues value i - 1 (+ 1, v_rcp_f32) and finishes
+// value i - 2 (1 - 2 r; every second gap the conversion of a pair) - three independent short chains per gap instead of one
+// dependent chain of six.  A gap is closed by a scheduling barrier: the compiler may order the handful of instructions inside
+// it, nothing moves across (left alone it issues a tile's MFMAs in one burst and the activations after them).
+// Pure arithmetic floats freely between the barriers when the compiler linearises the unrolled body (it ended up behind all of
+// them): every value that crosses a gap boundary is therefore "pinned" - an empty asm statement that redefines it - at the start
+// of the gap that consumes it and at the end of the gap that produced it.  The pins and the barriers are ordered among
+// themselves, so an operation sits between its input's pin and its output's.  No instruction is emitted for a pin.
+#define SKP_PIN(v) asm volatile("" : "+v"(v))
+#define SKP_PIN_S(v) asm volatile("" : "+s"(v))
+struct SkpAct {
+  float e[16], r[16];
+  uint32_t w[8];
+  float hprev;
+};
+__device__ __forceinline__ void skp_act_gap(SkpAct &a, const int i, const skp_f32x16 &acc) {
+  const bool sa = i < 16, sb = i >= 1 && i <= 16, sc = i >= 2 && i <= 17, pair = sc && ((i - 2) & 1);
+  float ein = 0.f, rin = 0.f, eo = 0.f, ro = 0.f, hv = 0.f;
+  uint32_t w = 0;
+  if (sb) {
+    ein = a.e[i - 1];
+    SKP_PIN(ein);
+  }
+  if (sc) {
+    rin = a.r[i - 2];
+    SKP_PIN(rin);
+  }
+  if (sa) eo = __builtin_amdgcn_exp2f(acc[i]);  // (the accumulator IS (2 / ln 2) (w x + b): scaled weights, bias as its initial value)
+  if (sb) ro = __builtin_amdgcn_rcpf(ein + 1.0f);
+  if (sc) {
+    hv = __builtin_fmaf(rin, -2.0f, 1.0f);
+    if (pair) w = skp_pk(a.hprev, hv);
+  }
+  if (sa) {
+    SKP_PIN(eo);
+    a.e[i] = eo;
+  }
+  if (sb) {
+    SKP_PIN(ro);
+    a.r[i - 1] = ro;
+  }
+  if (pair) {
+    SKP_PIN(w);
+    a.w[(i - 2) >> 1] = w;
+  } else if (sc) {
+    SKP_PIN(hv);
+    a.hprev = hv;
+  }
+}
+#define SKP_GAP_END __builtin_amdgcn_sched_barrier(0)
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 mode (SKYJO_MLP_BF16): single bf16 weights and inter-layer activations, float32 accumulation.
+// LDS: the 256 x 256 layer (128 KB), layer 3 (16 KB), layer 2's scaled bias (1 KB).
+// ------------------------------------------------------------------------------------------------------------------
+// Stage U of layers 2 / 3: the 16 MFMAs of tile U + 1 (gaps 0 .. 15) and layer 3's two k-steps of tile U - 1 (gaps 16, 17) between
+// the activations of tile U.  a0 / a1: the weight fragments of the first two MFMAs (read two gaps ahead, like all the others).
+template <int U>
+__device__ __forceinline__ void skp_stage_bf16(const uint4 *w2s, const uint4 *w3s, const float *b2s, const int lane, const int h,
+                                               const skp_bf16x8 (&h1)[16], skp_f32x16 &cur, skp_f32x16 &acc3, skp_bf16x8 &f0, skp_bf16x8 &f1,
+                                               skp_bf16x8 &a0, skp_bf16x8 &a1, skp_f32x16 &bias_next) {
+  skp_f32x16 nxt = bias_next;  // (scaled) bias of tile U + 1: the chain's initial accumulator
+  skp_bf16x8 a[20];
+  a[0] = a0, a[1] = a1;
+  SkpAct act;
+  skp_f32x16 bn;
+#pragma unroll
+  for (int i = 0; i < 18; i++) {
+    // LDS reads, two gaps ahead of their MFMA: the rest of chain U + 1, layer 3's fragments, the head of chain U + 2
+    if (i + 2 < 16) {
+      if (U < 7) a[i + 2] = skp_frag(w2s + ((U + 1) * 16 + i + 2) * 64 + lane);
+    } else if (i + 2 < 18) {
+      if (U > 0) a[i + 2] = skp_frag(w3s + (2 * (U - 1) + (i + 2 - 16)) * 64 + lane);
+    } else if (U < 6) {
+      a[i + 2] = skp_frag(w2s + ((U + 2) * 16 + (i - 16)) * 64 + lane);
+    }
+    if (U < 6 && i >= 8 && i < 12) {  // tile U + 2's bias (every lane half reads the same 16 bytes: a broadcast)
+      const int q = i - 8;
+      const float4 b = *(const float4 *)(b2s + 32 * (U + 2) + 8 * q + 4 * h);
+      bn[4 * q] = b.x, bn[4 * q + 1] = b.y, bn[4 * q + 2] = b.z, bn[4 * q + 3] = b.w;
+    }
+    if (i < 16) {
+      if (U < 7) nxt = SKP_MFMA(a[i], h1[i], nxt);
+    } else if (U > 0) {
+      acc3 = SKP_MFMA(a[i], i == 16 ? f0 : f1, acc3);
+    }
+    skp_act_gap(act, i, cur);
+    SKP_GAP_END;
+  }
+  f0 = skp_frag4((const uint32_t(&)[4])act.w[0]), f1 = skp_frag4((const uint32_t(&)[4])act.w[4]);
+  cur = nxt;
+  if (U < 6) a0 = a[18], a1 = a[19], bias_next = bn;
+}
+__device__ __forceinline__ skp_f32x16 skp_bias_tile(const float *b2s, const int u, const int h) {
+  skp_f32x16 r;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const float4 b = *(const float4 *)(b2s + 32 * u + 8 * q + 4 * h);
+    r[4 * q] = b.x, r[4 * q + 1] = b.y, r[4 * q + 2] = b.z, r[4 * q + 3] = b.w;
+  }
+  return r;
+}
+
+// One batch of 256 games (32 per wavefront).  FIRST: the workgroup's first batch, which also brings the weights of layers 2 and 3
+// into LDS; `more`: another batch follows (its record is requested behind layer 1).
+template <bool FIRST>
+__device__ __forceinline__ void skp_batch_bf16(const SkMlpDev &net, const SkMlpRecords &R, float *const out, const SkMlpDraw &draw, uint4 *w2s,
+                                               uint4 *w3s, float *b2s, const long long batch, const bool more, const int lane, const int wave,
+                                               const int col, const int h, uint32_t (&ob)[8]) {
+  SKP_STAMP_DECL;
+  const long long g = (batch * SKP_WG + wave) * 32 + col;
+  // ---- what this batch reads from memory, up front: layer 1's sixteen fragments (their 64 registers are the ones its results
+  // grow into), layer 3's bias; the record was requested before the loop / behind the previous batch's layer 1 ----
+  skp_bf16x8 x[2], w1f[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) w1f[k] = skp_frag(net.w1 + k * 64 + lane);
+  skp_f32x16 acc3;
+  {
+    const float4 *bp = (const float4 *)(net.b3 + (size_t)lane * 16);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float4 b = bp[q];
+      acc3[4 * q] = b.x, acc3[4 * q + 1] = b.y, acc3[4 * q + 2] = b.z, acc3[4 * q + 3] = b.w;
+    }
+  }
+  // In the first batch the weights of layers 2 and 3 travel behind them, 18 KB per wavefront through registers (pieces (8 j + w)
+  // of the 128 + 16 one-KiB pieces), and are written to LDS between layer 1's activations as they arrive.  (LDS-DMA needs no
+  // registers, but a piece costs the issuing wavefront 100 - 180 cycles and the 144 KB took ~ 20 000 cycles to land - stamped;
+  // the registers are free here: layer 1's results have not been produced yet.)
+  skp_u32x4 stg[18];  // (a native vector type: HIP's uint4 is a struct of unions, and an array of them stays in scratch)
+  if (FIRST) {
+    if (threadIdx.x < SKP_HIDDEN) b2s[threadIdx.x] = net.b2[threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < 18; j++)
+      stg[j] = *(const skp_u32x4 *)(j < 16 ? net.w2 + (j * 8 + wave) * 64 + lane : net.w3 + ((j - 16) * 8 + wave) * 64 + lane);
+  }
+  skp_inputs(R, ob, h, x);
+  SKP_STAMP(1 + 14 * (FIRST ? 0 : 1));
+  // ---- layer 1: 31 (+1) -> 256, tanh (the bias rides in the product: feature 31 is 1); the result tiles become the 16
+  // k-step fragments of layer 2.  Tile t + 1's two MFMAs sit in the first gaps of tile t's activations ----
+  skp_bf16x8 h1[16];
+  {
+    skp_f32x16 acc = SKP_MFMA(w1f[0], x[0], skp_zero());
+    acc = SKP_MFMA(w1f[1], x[1], acc);
+    SKP_GAP_END;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      SkpAct act;
+      skp_f32x16 nxt;
+#pragma unroll
+      for (int i = 0; i < 18; i++) {
+        if (t < 7 && i == 0) nxt = SKP_MFMA(w1f[2 * t + 2], x[0], skp_zero());
+        if (t < 7 && i == 1) nxt = SKP_MFMA(w1f[2 * t + 3], x[1], nxt);
+        if (FIRST && (i == 5 || i == 11)) {
+          const int j = 2 * t + (i == 11);
+          *(skp_u32x4 *)(w2s + (j * 8 + wave) * 64 + lane) = stg[j];
+          if (t == 7) *(skp_u32x4 *)(w3s + ((i == 11) * 8 + wave) * 64 + lane) = stg[16 + (i == 11)];
+        }
+        skp_act_gap(act, i, acc);
+        SKP_GAP_END;
+      }
+      h1[2 * t] = skp_frag4((const uint32_t(&)[4])act.w[0]), h1[2 * t + 1] = skp_frag4((const uint32_t(&)[4])act.w[4]);
+      acc = nxt;
+    }
+  }
+  SKP_STAMP(3 + 14 * (FIRST ? 0 : 1));
+  if (FIRST) __syncthreads();  // everybody's share of the weights is in LDS
+  // the next batch's record, requested now: it arrives while layers 2 and 3 run
+  if (more) skp_record_load(R, ((batch + 1) * SKP_WG + wave) * 32 + col, ob);
+  SKP_STAMP(4 + 14 * (FIRST ? 0 : 1));
+  // ---- layers 2 and 3 ----
+  skp_f32x16 cur = skp_bias_tile(b2s, 0, h), bias_next = skp_bias_tile(b2s, 1, h);
+#pragma unroll
+  for (int ks = 0; ks < 16; ks++) cur = SKP_MFMA(skp_frag(w2s + ks * 64 + lane), h1[ks], cur);
+  skp_bf16x8 f0, f1, a0 = skp_frag(w2s + 16 * 64 + lane), a1 = skp_frag(w2s + 17 * 64 + lane);
+  SKP_GAP_END;
+  SKP_STAMP(5 + 14 * (FIRST ? 0 : 1));
+  skp_stage_bf16<0>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  SKP_STAMP(6 + 14 * (FIRST ? 0 : 1));
+  skp_stage_bf16<1>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  SKP_STAMP(7 + 14 * (FIRST ? 0 : 1));
+  skp_stage_bf16<2>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  SKP_STAMP(8 + 14 * (FIRST ? 0 : 1));
+  skp_stage_bf16<3>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  SKP_STAMP(9 + 14 * (FIRST ? 0 : 1));
+  skp_stage_bf16<4>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  SKP_STAMP(10 + 14 * (FIRST ? 0 : 1));
+  skp_stage_bf16<5>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  SKP_STAMP(11 + 14 * (FIRST ? 0 : 1));
+  skp_stage_bf16<6>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  SKP_STAMP(12 + 14 * (FIRST ? 0 : 1));
+  skp_stage_bf16<7>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  acc3 = SKP_MFMA(skp_frag(w3s + 14 * 64 + lane), f0, acc3);
+  acc3 = SKP_MFMA(skp_frag(w3s + 15 * 64 + lane), f1, acc3);
+  SKP_STAMP(13 + 14 * (FIRST ? 0 : 1));
+  skp_finish(acc3, lane, g, R, net.out_dim, out, draw);
+  SKP_STAMP(14 + 14 * (FIRST ? 0 : 1));
+}
+
+__global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_bf16(const SkMlpArgs A) {
+  __shared__ uint4 w2s[8 * 16 * 64];
+  __shared__ uint4 w3s[16 * 64];
+  __shared__ float b2s[SKP_HIDDEN];
+  // (the branch's descriptor is read from the kernel-argument segment by index: one set of scalar registers, not two and a select)
+  const SkMlpDev &net = A.net[blockIdx.y];
+  float *const out = A.out[blockIdx.y];
+  const SkMlpRecords &R = A.R;
+  const int passes = A.passes;
+  SkMlpDraw draw = A.draw;
+  draw.enable = blockIdx.y ? 0 : A.draw.enable;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = lane & 31, h = lane >> 5;
+  SKP_STAMP_DECL;
+  SKP_STAMP(0);
+  SKP_RSTAMP(29);
+  uint32_t ob[8];
+  skp_record_load(R, ((long long)blockIdx.x * passes * SKP_WG + wave) * 32 + col, ob);
+  skp_batch_bf16<true>(net, R, out, draw, w2s, w3s, b2s, (long long)blockIdx.x * passes, passes > 1, lane, wave, col, h, ob);
+  for (int pass = 1; pass < passes; pass++) {
+    const long long batch = (long long)blockIdx.x * passes + pass;
+    if (batch * SKP_GAMES_PER_WG >= R.n) break;  // (uniform: a workgroup's later batches may lie beyond the last game)
+    skp_batch_bf16<false>(net, R, out, draw, w2s, w3s, b2s, batch, pass + 1 < passes, lane, wave, col, h, ob);
+  }
+  SKP_RSTAMP(30);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The float32-grade form (SKYJO_MLP_FP32).  The reference evaluates RLlib's TorchFC in float32
+// (rlskyjo/models/action_mask_model.py:43-49); bf16 operands alone leave the logits 8e-2 away from it.  Here every operand
+// of every product is the sum of two bf16 values - w = w_hi + w_lo, h = h_hi + h_lo, 16 significant bits each - and a
+// product is three MFMAs into the same float32 accumulator, w_hi h_lo + w_lo h_hi + w_hi h_hi (w_lo h_lo, 2^-16 of the
+// product, is left out): the logits and values agree with the float32 module to 1e-4 (tests/test_gpu_policy_net.py) at
+// three times the matrix work of the bf16 form.  The observations are int8 and exact in one bf16, so layer 1 takes two.
+//   * 48 MFMAs per output tile of layer 2 and 6 of layer 3 against 16 activations: the matrix pipe bounds this form.  A stage
+//     is 54 gaps; value v's activation is spread over gaps 3v + 2 .. 3v + 4, a pair's split into hi and lo over the three after.
+//   * The 256 x 256 layer is 256 KB (hi + lo) against 160 KB of LDS: it passes through two 64 KB buffers in quarters of two
+//     output tiles, each quarter requested by LDS-DMA two stages before its first MFMA; ONE workgroup barrier per quarter
+//     (everybody's share of the next quarter has landed, everybody is through with the buffer that is refilled next).
+//   * Layer 2's first chain (48 MFMAs) runs inside layer 1's activations, k-step by k-step as layer 1's tiles appear.
+// ------------------------------------------------------------------------------------------------------------------
+struct SkpActS {
+  float b[16], e[16], r[16], hv[16];
+  uint32_t hi[8], lo[8];
+  float da[8], db[8];
+};
+// The operations of gap g when value v's activation starts in gap G v + OFF (phases in consecutive gaps: multiply-add + v_exp, + 1
+// + v_rcp, 1 - 2 r) and the split of pair p = (2p, 2p + 1) into hi and lo follows in the three gaps after its second value; the
+// bias of value v is read (ds_read_b32: two addresses per wavefront, a broadcast) two gaps before it is used.
+template <bool BIAS, int G, int OFF>
+__device__ __forceinline__ void skp_act_split_gap(SkpActS &a, const int g, const skp_f32x16 &acc, const float *b2row, const int h) {
+  // (no loops over v or p here: g is a constant once the caller's gap loop is unrolled, and so is everything derived from it)
+  const int tbias = g + 2 - OFF, ta = g - OFF, tb = ta - 1, tc = ta - 2;
+  if (BIAS && tbias >= 0 && tbias % G == 0 && tbias / G < 16) {
+    const int v = tbias / G;
+    a.b[v] = b2row[(v & 3) + 8 * (v >> 2) + 4 * h];
+  }
+  if (ta >= 0 && ta % G == 0 && ta / G < 16) {
+    const int v = ta / G;
+    float eo;
+    if (BIAS) {
+      float b = a.b[v];
+      SKP_PIN(b);
+      eo = __builtin_amdgcn_exp2f(acc[v] + b);
+    } else {
+      eo = __builtin_amdgcn_exp2f(acc[v]);
+    }
+    SKP_PIN(eo);
+    a.e[v] = eo;
+  }
+  if (tb >= 0 && tb % G == 0 && tb / G < 16) {
+    const int v = tb / G;
+    float ein = a.e[v];
+    SKP_PIN(ein);
+    float ro = __builtin_amdgcn_rcpf(ein + 1.0f);
+    SKP_PIN(ro);
+    a.r[v] = ro;
+  }
+  if (tc >= 0 && tc % G == 0 && tc / G < 16) {
+    const int v = tc / G;
+    float rin = a.r[v];
+    SKP_PIN(rin);
+    float hv = __builtin_fmaf(rin, -2.0f, 1.0f);
+    SKP_PIN(hv);
+    a.hv[v] = hv;
+  }
+  const int tp = g - OFF - 3 - G, tq = tp - 1, tr = tp - 2;  // pair p's three gaps start at G (2p + 1) + OFF + 3
+  if (tp >= 0 && tp % (2 * G) == 0 && tp / (2 * G) < 8) {
+    const int p = tp / (2 * G);
+    float x0 = a.hv[2 * p], x1 = a.hv[2 * p + 1];
+    SKP_PIN(x0);
+    SKP_PIN(x1);
+    uint32_t w = skp_pk(x0, x1);
+    SKP_PIN(w);
+    a.hv[2 * p] = x0, a.hv[2 * p + 1] = x1, a.hi[p] = w;
+  }
+  if (tq >= 0 && tq % (2 * G) == 0 && tq / (2 * G) < 8) {
+    const int p = tq / (2 * G);
+    uint32_t w = a.hi[p];
+    float x0 = a.hv[2 * p], x1 = a.hv[2 * p + 1];
+    SKP_PIN(w);
+    SKP_PIN(x0);
+    SKP_PIN(x1);
+    float d0 = x0 - __uint_as_float(w << 16), d1 = x1 - __uint_as_float(w & 0xffff0000u);
+    SKP_PIN(d0);
+    SKP_PIN(d1);
+    a.hi[p] = w, a.da[p] = d0, a.db[p] = d1;
+  }
+  if (tr >= 0 && tr % (2 * G) == 0 && tr / (2 * G) < 8) {
+    const int p = tr / (2 * G);
+    float d0 = a.da[p], d1 = a.db[p];
+    SKP_PIN(d0);
+    SKP_PIN(d1);
+    uint32_t w = skp_pk(d0, d1);
+    SKP_PIN(w);
+    a.lo[p] = w;
+  }
+}
+#define SKP_SPLIT_GAPS 54  // a stage of layers 2 / 3: G = 3, OFF = 2
+#define SKP_L1_GAPS 21     // a tile of layer 1: G = 1, OFF = 0
+
+// one quarter of the 256 x 256 layer (output tiles 2q, 2q + 1: [tile][hi, lo][16 k-steps][64 lanes] = 64 KB) on its way into a
+// buffer: 8 KB per wavefront
+__device__ __forceinline__ void skp_dma_quarter(const SkMlpDev &net, const int q, const uint32_t lds_buf, const int wave, const int lane) {
+  const int tt = wave >> 2, hl = (wave >> 1) & 1, half = wave & 1;
+  const uint8_t *src = (const uint8_t *)((hl ? net.w2l : net.w2) + (size_t)(2 * q + tt) * 1024 + half * 512);
+  const uint32_t dst = lds_buf + (uint32_t)(((tt * 2 + hl) * 1024 + half * 512) * 16);
+  skp_dma4k(src, (uint32_t)lane * 16, dst);
+  skp_dma4k(src + 4096, (uint32_t)lane * 16, dst + 4096);
+}
+
+// Stage U: layer 3's six MFMAs of tile U - 1 (gaps 0 .. 5), the 48 MFMAs of tile U + 1 (gaps 6 .. 53), the activations of tile U.
+// The weight fragments (hi, lo) of a k-step are read three gaps ahead of its first MFMA; w3f: layer 3's four fragments for tile
+// U - 1 (hi, lo of k-steps 2 (U - 1), 2 (U - 1) + 1), replaced by tile U's on the way.
+template <int U>
+__device__ __forceinline__ void skp_stage_split(const SkMlpDev &net, const uint4 *wq, const float *b2s, const int lane, const int h,
+                                                const skp_bf16x8 (&h1h)[16], const skp_bf16x8 (&h1l)[16], skp_f32x16 &cur, skp_f32x16 &acc3,
+                                                skp_bf16x8 (&fh)[2], skp_bf16x8 (&fl)[2], skp_bf16x8 (&w3f)[4]) {
+  // tile U + 1 lives in buffer ((U + 1) >> 1) & 1 as tile (U + 1) & 1 of its quarter
+  const uint4 *wt = wq + (((U + 1) >> 1) & 1) * 4096 + ((U + 1) & 1) * 2048 + lane;
+  skp_f32x16 nxt = skp_zero();
+  SkpActS act;
+  skp_bf16x8 ah, al, nh, nl, w3n[4];
+#pragma unroll
+  for (int g = 0; g < SKP_SPLIT_GAPS; g++) {
+    const int m = g - 6, ks = m / 3, part = m % 3;
+    if (U < 7 && g == 3) ah = skp_frag(wt), al = skp_frag(wt + 1024);
+    if (U < 7 && m >= 0 && part == 0 && ks < 15) nh = skp_frag(wt + (ks + 1) * 64), nl = skp_frag(wt + 1024 + (ks + 1) * 64);
+    if (g >= 40 && g < 44) w3n[g - 40] = skp_frag(((g - 40) & 1 ? net.w3l : net.w3) + (2 * U + ((g - 40) >> 1)) * 64 + lane);
+    if (g < 6) {
+      if (U > 0) {
+        const int s = g / 3, k = g % 3;
+        acc3 = SKP_MFMA(k == 1 ? w3f[2 * s + 1] : w3f[2 * s], k == 0 ? fl[s] : fh[s], acc3);
+      }
+    } else if (U < 7) {
+      nxt = SKP_MFMA(part == 1 ? al : ah, part == 0 ? h1l[ks] : h1h[ks], nxt);
+      if (part == 2 && ks < 15) ah = nh, al = nl;
+    }
+    skp_act_split_gap<true, 3, 2>(act, g, cur, b2s + 32 * U, h);
+    SKP_GAP_END;
+  }
+  fh[0] = skp_frag4((const uint32_t(&)[4])act.hi[0]), fh[1] = skp_frag4((const uint32_t(&)[4])act.hi[4]);
+  fl[0] = skp_frag4((const uint32_t(&)[4])act.lo[0]), fl[1] = skp_frag4((const uint32_t(&)[4])act.lo[4]);
+#pragma unroll
+  for (int k = 0; k < 4; k++) w3f[k] = w3n[k];
+  cur = nxt;
+}
+
+__global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_split(const SkMlpArgs A) {
+  __shared__ uint4 wq[2 * 4096];  // two quarters
+  __shared__ float b2s[SKP_HIDDEN];
+  // (the branch's descriptor is read from the kernel-argument segment by index: one set of scalar registers, not two and a select)
+  const SkMlpDev &net = A.net[blockIdx.y];
+  float *const out = A.out[blockIdx.y];
+  const SkMlpRecords &R = A.R;
+  const int passes = A.passes;
+  SkMlpDraw draw = A.draw;
+  draw.enable = blockIdx.y ? 0 : A.draw.enable;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = lane & 31, h = lane >> 5;
+  const uint32_t buf0 = SKP_LDS32(wq), buf1 = buf0 + 65536;
+  skp_dma_quarter(net, 0, buf0, wave, lane);
+  if (threadIdx.x < SKP_HIDDEN) b2s[threadIdx.x] = net.b2[threadIdx.x];
+  for (int pass = 0; pass < passes; pass++) {
+    const long long batch = (long long)blockIdx.x * passes + pass;
+    if (batch * SKP_GAMES_PER_WG >= R.n && pass > 0) break;
+    const bool more = pass + 1 < passes && (batch + 1) * SKP_GAMES_PER_WG < R.n;  // this workgroup has another batch
+    const long long g = (batch * SKP_WG + wave) * 32 + col;
+    skp_bf16x8 x[2];
+    {
+      uint32_t ob[8];
+      skp_record_load(R, g, ob);
+      skp_inputs(R, ob, h, x);
+    }
+    // quarter 0 has landed (requested before the loop / behind the previous batch's stage 4); quarter 1 goes into the other buffer
+    skp_vm_drain();
+    __syncthreads();
+    skp_dma_quarter(net, 1, buf1, wave, lane);
+    // ---- layer 1: (hi + lo) weights x exact inputs, activations split into hi + lo; layer 2's first chain (output tile 0) follows
+    // it k-step by k-step: tile t - 1's two k-steps between the activations of tile t ----
+    skp_bf16x8 h1h[16], h1l[16];
+    skp_f32x16 cur = skp_zero();
+    {
+      skp_bf16x8 w1f[4];  // [lo, hi of k-step 0, lo, hi of k-step 1]
+#pragma unroll
+      for (int k = 0; k < 4; k++) w1f[k] = skp_frag(((k & 1) ? net.w1 : net.w1l) + (k >> 1) * 64 + lane);
+      skp_f32x16 acc = skp_zero();
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc = SKP_MFMA(w1f[k], x[k >> 1], acc);
+#pragma unroll
+      for (int k = 0; k < 4; k++) w1f[k] = skp_frag(((k & 1) ? net.w1 : net.w1l) + (2 + (k >> 1)) * 64 + lane);
+      SKP_GAP_END;
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        SkpActS act;
+        skp_f32x16 nxt = skp_zero();
+        skp_bf16x8 c0h, c0l, c1h, c1l;
+        const int ks0 = 2 * (t - 1), ks1 = ks0 + 1;
+#pragma unroll
+        for (int gp = 0; gp < SKP_L1_GAPS; gp++) {
+          if (t < 7 && gp < 4) nxt = SKP_MFMA(w1f[gp], x[gp >> 1], nxt);
+          if (t < 6 && gp >= 4 && gp < 8)
+            w1f[gp - 4] = skp_frag((((gp - 4) & 1) ? net.w1 : net.w1l) + ((t + 2) * 2 + ((gp - 4) >> 1)) * 64 + lane);
+          if (t >= 1) {
+            if (gp == 2) c0h = skp_frag(wq + ks0 * 64 + lane), c0l = skp_frag(wq + 1024 + ks0 * 64 + lane);
+            if (gp == 8) c1h = skp_frag(wq + ks1 * 64 + lane), c1l = skp_frag(wq + 1024 + ks1 * 64 + lane);
+            if (gp >= 6 && gp < 9) cur = SKP_MFMA(gp == 7 ? c0l : c0h, gp == 6 ? h1l[ks0] : h1h[ks0], cur);
+            if (gp >= 12 && gp < 15) cur = SKP_MFMA(gp == 13 ? c1l : c1h, gp == 12 ? h1l[ks1] : h1h[ks1], cur);
+          }
+          skp_act_split_gap<false, 1, 0>(act, gp, acc, nullptr, h);
+          SKP_GAP_END;
+        }
+        h1h[2 * t] = skp_frag4((const uint32_t(&)[4])act.hi[0]), h1h[2 * t + 1] = skp_frag4((const uint32_t(&)[4])act.hi[4]);
+        h1l[2 * t] = skp_frag4((const uint32_t(&)[4])act.lo[0]), h1l[2 * t + 1] = skp_frag4((const uint32_t(&)[4])act.lo[4]);
+        acc = nxt;
+      }
+#pragma unroll
+      for (int ks = 14; ks < 16; ks++) {
+        const skp_bf16x8 ch = skp_frag(wq + ks * 64 + lane), cl = skp_frag(wq + 1024 + ks * 64 + lane);
+        cur = SKP_MFMA(ch, h1l[ks], cur);
+        cur = SKP_MFMA(cl, h1h[ks], cur);
+        cur = SKP_MFMA(ch, h1h[ks], cur);
+      }
+    }
+    // ---- layers 2 and 3 ----
+    skp_f32x16 acc3;
+    {
+      const float4 *bp = (const float4 *)(net.b3 + (size_t)lane * 16);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float4 b = bp[q];
+        acc3[4 * q] = b.x, acc3[4 * q + 1] = b.y, acc3[4 * q + 2] = b.z, acc3[4 * q + 3] = b.w;
+      }
+    }
+    skp_bf16x8 fh[2], fl[2], w3f[4];
+    SKP_GAP_END;
+    skp_stage_split<0>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
+    skp_vm_drain();
+    __syncthreads();  // quarter 1 is there, quarter 0's buffer is free
+    skp_dma_quarter(net, 2, buf0, wave, lane);
+    skp_stage_split<1>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
+    skp_stage_split<2>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
+    skp_vm_drain();
+    __syncthreads();
+    skp_dma_quarter(net, 3, buf1, wave, lane);
+    skp_stage_split<3>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
+    skp_stage_split<4>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
+    skp_vm_drain();
+    __syncthreads();
+    if (more) skp_dma_quarter(net, 0, buf0, wave, lane);
+    skp_stage_split<5>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
+    skp_stage_split<6>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
+    skp_stage_split<7>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+      acc3 = SKP_MFMA(w3f[2 * s2], fl[s2], acc3);
+      acc3 = SKP_MFMA(w3f[2 * s2 + 1], fh[s2], acc3);
+      acc3 = SKP_MFMA(w3f[2 * s2], fh[s2], acc3);
+    }
+    skp_finish(acc3, lane, g, R, net.out_dim, out, draw);
+  }
+}
+
+int sk_launch_mlp(const SkMlpDev &a, const SkMlpDev &b, int nets, const SkMlpRecords &r, float *out_a, const SkMlpDraw &draw,
+                  float *out_b, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  const long long batches = (r.n + SKP_GAMES_PER_WG - 1) / SKP_GAMES_PER_WG;
+  // one round of workgroups where the batch allows it: a workgroup owns a CU (its LDS), 256 CUs, `nets` workgroups per batch
+  int passes = (int)((batches * nets + 255) / 256);
+  if (passes < 1) passes = 1;
+  if (passes > 8) passes = 8;
+  const dim3 grid((unsigned)((batches + passes - 1) / passes), (unsigned)nets), block(64 * SKP_WG);
+  SkMlpArgs A;
+  A.net[0] = a, A.net[1] = b, A.out[0] = out_a, A.out[1] = out_b, A.R = r, A.draw = draw, A.passes = passes;
+  if (a.split)
+    hipExtLaunchKernelGGL(k_net_split, grid, block, 0, s, e0, e1, 0, A);
+  else
+    hipExtLaunchKernelGGL(k_net_bf16, grid, block, 0, s, e0, e1, 0, A);
+  return (int)hipGetLastError();
+}
