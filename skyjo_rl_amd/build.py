@@ -11,7 +11,8 @@ HEADERS = [os.path.join(CSRC, h) for h in ("skyjo_device.h", "skyjo_layout.h", "
 # Two translation units, each with the instruction scheduler that suits it (EXPERIMENTS.md round 5 #11, round 6): the
 # environment kernels gain 1 - 2 % under max-ilp, the policy net's hand-placed MFMA gaps want the default strategy.
 UNITS = [("skyjo_capi", os.path.join(CSRC, "skyjo_capi.hip"), ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
-         ("skyjo_policy", os.path.join(CSRC, "skyjo_policy.hip"), [])]
+         # (the net kernels are straight-line code: their gap loops must unroll completely, whatever the size)
+         ("skyjo_policy", os.path.join(CSRC, "skyjo_policy.hip"), ["-mllvm", "-unroll-threshold=100000", "-mllvm", "-pragma-unroll-threshold=1000000"])]
 SRC = UNITS[0][1]
 DEPS = [u[1] for u in UNITS] + HEADERS
 OUT = os.path.join(HERE, "libskyjo_vec.so")

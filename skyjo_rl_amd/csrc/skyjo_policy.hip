@@ -29,6 +29,7 @@
 typedef __bf16 skp_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float skp_f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t skp_u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) float *skp_lds_f32;  // (an LDS pointer that stays one: ds_read, not flat_load)
 #define SKP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 #define SKP_LDS32(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(p))
 
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
   uint32_t ob[8];
   skp_record_load(R, ((long long)blockIdx.x * passes * SKP_WG + wave) * 32 + col, ob);
   skp_batch_bf16<true>(net, R, out, draw, w2s, w3s, b2s, (long long)blockIdx.x * passes, passes > 1, lane, wave, col, h, ob);
+#pragma unroll 1
   for (int pass = 1; pass < passes; pass++) {
     const long long batch = (long long)blockIdx.x * passes + pass;
     if (batch * SKP_GAMES_PER_WG >= R.n) break;  // (uniform: a workgroup's later batches may lie beyond the last game)
@@ -434,15 +436,18 @@ struct SkpActS {
 };
 // The operations of gap g when value v's activation starts in gap G v + OFF (phases in consecutive gaps: multiply-add + v_exp, + 1
 // + v_rcp, 1 - 2 r) and the split of pair p = (2p, 2p + 1) into hi and lo follows in the three gaps after its second value; the
-// bias of value v is read (ds_read_b32: two addresses per wavefront, a broadcast) two gaps before it is used.
+// bias of value v is read (ds_read_b32: two addresses per wavefront, a broadcast) two gaps before it is used; b2row is the tile's
+// row of this lane's half (b2s + 32 u + 4 h) as ONE opaque register + constant offsets (left to itself the compiler computed all
+// 128 addresses ahead of the loop and spilled them).
 template <bool BIAS, int G, int OFF>
-__device__ __forceinline__ void skp_act_split_gap(SkpActS &a, const int g, const skp_f32x16 &acc, const float *b2row, const int h) {
+__device__ __forceinline__ void skp_act_split_gap(SkpActS &a, const int g, const skp_f32x16 &acc, skp_lds_f32 b2row, const int h) {
   // (no loops over v or p here: g is a constant once the caller's gap loop is unrolled, and so is everything derived from it)
   const int tbias = g + 2 - OFF, ta = g - OFF, tb = ta - 1, tc = ta - 2;
   if (BIAS && tbias >= 0 && tbias % G == 0 && tbias / G < 16) {
     const int v = tbias / G;
-    a.b[v] = b2row[(v & 3) + 8 * (v >> 2) + 4 * h];
+    a.b[v] = b2row[(v & 3) + 8 * (v >> 2)];
   }
+  if (BIAS && OFF < 2 && g == 0) a.b[0] = b2row[0];  // (value 0 starts before gap 2: its bias is read in the first gap)
   if (ta >= 0 && ta % G == 0 && ta / G < 16) {
     const int v = ta / G;
     float eo;
@@ -507,55 +512,72 @@ __device__ __forceinline__ void skp_act_split_gap(SkpActS &a, const int g, const
 #define SKP_SPLIT_GAPS 54  // a stage of layers 2 / 3: G = 3, OFF = 2
 #define SKP_L1_GAPS 21     // a tile of layer 1: G = 1, OFF = 0
 
-// one quarter of the 256 x 256 layer (output tiles 2q, 2q + 1: [tile][hi, lo][16 k-steps][64 lanes] = 64 KB) on its way into a
-// buffer: 8 KB per wavefront
-__device__ __forceinline__ void skp_dma_quarter(const SkMlpDev &net, const int q, const uint32_t lds_buf, const int wave, const int lane) {
-  const int tt = wave >> 2, hl = (wave >> 1) & 1, half = wave & 1;
-  const uint8_t *src = (const uint8_t *)((hl ? net.w2l : net.w2) + (size_t)(2 * q + tt) * 1024 + half * 512);
-  const uint32_t dst = lds_buf + (uint32_t)(((tt * 2 + hl) * 1024 + half * 512) * 16);
-  skp_dma4k(src, (uint32_t)lane * 16, dst);
-  skp_dma4k(src + 4096, (uint32_t)lane * 16, dst + 4096);
+// One output tile of the 256 x 256 layer in LDS: [hi, lo][16 k-steps][64 lanes] fragments = 32 KB; a ring of three of them.
+// A wavefront's share of a tile on its way from memory: pieces 4 w .. 4 w + 3 of its 32 one-KiB pieces, through registers
+// (LDS-DMA needs none, but a piece costs the issuing wavefront 100 - 180 cycles and arrives slowly - stamped in round 6 -, and
+// every other vector-memory operation of the wavefront queues behind it).
+#define SKP_TILE_U4 2048
+struct SkpStage {
+  skp_u32x4 r[2];
+};
+__device__ __forceinline__ void skp_stage_load(const SkMlpDev &net, const int tile, const int wave, const int lane, const int half, SkpStage &st) {
+  const uint4 *src = ((wave >> 2) ? net.w2l : net.w2) + (size_t)(tile & 7) * 1024 + (wave & 3) * 256 + half * 128 + lane;
+  st.r[0] = *(const skp_u32x4 *)src, st.r[1] = *(const skp_u32x4 *)(src + 64);
+}
+__device__ __forceinline__ void skp_stage_store(uint4 *slot_lane, const int wave, const int half, const int k, const SkpStage &st) {
+  *(skp_u32x4 *)(slot_lane + wave * 256 + half * 128 + k * 64) = st.r[k];
 }
 
-// Stage U: layer 3's six MFMAs of tile U - 1 (gaps 0 .. 5), the 48 MFMAs of tile U + 1 (gaps 6 .. 53), the activations of tile U.
-// The weight fragments (hi, lo) of a k-step are read three gaps ahead of its first MFMA; w3f: layer 3's four fragments for tile
-// U - 1 (hi, lo of k-steps 2 (U - 1), 2 (U - 1) + 1), replaced by tile U's on the way.
+// Stage U (54 gaps): the 48 MFMAs of tile U + 1 in gaps 0 .. 47 (k-step g / 3), the activations of tile U beside them (value v in
+// gaps 3 v + 1 .., the last pair's low halves in gap 51), layer 3's six MFMAs of the same tile U in gaps 48 .. 53 - its fragments
+// never outlive the stage -; on the side, tile U + 3 (the next batch's tiles 0, 1 from U = 5 on) travels into the ring slot that
+// tile U has just left, one KiB at a time.  The weight fragments (hi, lo) of a k-step are read three gaps ahead of its first
+// MFMA (k-step 0's by the stage before: ah / al), layer 3's (from LDS) in gaps 45 and 48.
 template <int U>
-__device__ __forceinline__ void skp_stage_split(const SkMlpDev &net, const uint4 *wq, const float *b2s, const int lane, const int h,
-                                                const skp_bf16x8 (&h1h)[16], const skp_bf16x8 (&h1l)[16], skp_f32x16 &cur, skp_f32x16 &acc3,
-                                                skp_bf16x8 (&fh)[2], skp_bf16x8 (&fl)[2], skp_bf16x8 (&w3f)[4]) {
-  // tile U + 1 lives in buffer ((U + 1) >> 1) & 1 as tile (U + 1) & 1 of its quarter
-  const uint4 *wt = wq + (((U + 1) >> 1) & 1) * 4096 + ((U + 1) & 1) * 2048 + lane;
+__device__ __forceinline__ void skp_stage_split(const SkMlpDev &net, uint4 *const (&rot)[3], const uint4 *w3s, const float *b2s, const int lane,
+                                                const int wave, const int h, const skp_bf16x8 (&h1h)[16], const skp_bf16x8 (&h1l)[16],
+                                                skp_f32x16 &cur, skp_f32x16 &acc3, skp_bf16x8 &ah, skp_bf16x8 &al, skp_lds_f32 bias_h) {
+  const uint4 *wt = rot[(U + 1) % 3];  // tile U + 1 (this lane's fragment of k-step 0, hi)
+  const uint4 *wn = rot[(U + 2) % 3];  // tile U + 2 (its k-step 0 is read on the way out)
+  uint4 *const wr = rot[U % 3];        // tile U's slot: free since the barrier before this stage
   skp_f32x16 nxt = skp_zero();
   SkpActS act;
-  skp_bf16x8 ah, al, nh, nl, w3n[4];
+  skp_u32x4 st;
+  skp_bf16x8 nh, nl, w3h, w3l;
 #pragma unroll
   for (int g = 0; g < SKP_SPLIT_GAPS; g++) {
-    const int m = g - 6, ks = m / 3, part = m % 3;
-    if (U < 7 && g == 3) ah = skp_frag(wt), al = skp_frag(wt + 1024);
-    if (U < 7 && m >= 0 && part == 0 && ks < 15) nh = skp_frag(wt + (ks + 1) * 64), nl = skp_frag(wt + 1024 + (ks + 1) * 64);
-    if (g >= 40 && g < 44) w3n[g - 40] = skp_frag(((g - 40) & 1 ? net.w3l : net.w3) + (2 * U + ((g - 40) >> 1)) * 64 + lane);
-    if (g < 6) {
-      if (U > 0) {
-        const int s = g / 3, k = g % 3;
-        acc3 = SKP_MFMA(k == 1 ? w3f[2 * s + 1] : w3f[2 * s], k == 0 ? fl[s] : fh[s], acc3);
-      }
-    } else if (U < 7) {
-      nxt = SKP_MFMA(part == 1 ? al : ah, part == 0 ? h1l[ks] : h1h[ks], nxt);
-      if (part == 2 && ks < 15) ah = nh, al = nl;
+    const int ks = g / 3, part = g % 3;
+    if (U < 7 && g < 48 && part == 0 && ks < 15) nh = skp_frag(wt + (ks + 1) * 64), nl = skp_frag(wt + 1024 + (ks + 1) * 64);
+    // layer 3's fragments: k-step 2 U into (w3h, w3l), k-step 2 U + 1 into (nh, nl) - free since k-step 15's pair moved on in gap 44
+    if (g == 45) w3h = skp_frag(w3s + (2 * U) * 64 + lane), w3l = skp_frag(w3s + 1024 + (2 * U) * 64 + lane);
+    if (g == 48) nh = skp_frag(w3s + (2 * U + 1) * 64 + lane), nl = skp_frag(w3s + 1024 + (2 * U + 1) * 64 + lane);
+    if (U < 7 && g >= 6 && g < 54 && (g - 6) % 12 == 0) {  // piece j of this wavefront's four of tile U + 3: requested in gap 6 + 12 j ...
+      const int j = (g - 6) / 12;
+      st = *(const skp_u32x4 *)(((wave >> 2) ? net.w2l : net.w2) + (size_t)((U + 3) & 7) * 1024 + (wave & 3) * 256 + j * 64 + lane);
     }
-    skp_act_split_gap<true, 3, 2>(act, g, cur, b2s + 32 * U, h);
+    if (U < 7 && g >= 16 && (g - 16) % 12 == 0) *(skp_u32x4 *)(wr + wave * 256 + ((g - 16) / 12) * 64) = st;  // ... written ten gaps on
+    if (g < 48) {
+      if (U < 7) {
+        nxt = SKP_MFMA(part == 1 ? al : ah, part == 0 ? h1l[ks] : h1h[ks], nxt);
+        if (part == 2 && ks < 15) ah = nh, al = nl;
+      }
+    } else {
+      // layer 3, k-steps 2 U (gaps 48 .. 50) and 2 U + 1 (gaps 51 .. 53: its low halves come last, they are ready in gap 51)
+      const int s2 = (g - 48) / 3, k = (g - 48) % 3;
+      const skp_bf16x8 fhi = skp_frag4((const uint32_t(&)[4])act.hi[4 * s2]), flo = skp_frag4((const uint32_t(&)[4])act.lo[4 * s2]);
+      acc3 = SKP_MFMA(s2 ? (k == 1 ? nl : nh) : (k == 1 ? w3l : w3h), k == 2 ? flo : fhi, acc3);
+    }
+    if (U < 6 && g == 51) w3h = skp_frag(wn), w3l = skp_frag(wn + 1024);  // (tile U + 2's first pair, into the registers layer 3's first k-step has left)
+    skp_act_split_gap<true, 3, 1>(act, g, cur, bias_h + 32 * U, h);
     SKP_GAP_END;
   }
-  fh[0] = skp_frag4((const uint32_t(&)[4])act.hi[0]), fh[1] = skp_frag4((const uint32_t(&)[4])act.hi[4]);
-  fl[0] = skp_frag4((const uint32_t(&)[4])act.lo[0]), fl[1] = skp_frag4((const uint32_t(&)[4])act.lo[4]);
-#pragma unroll
-  for (int k = 0; k < 4; k++) w3f[k] = w3n[k];
   cur = nxt;
+  if (U < 6) ah = w3h, al = w3l;
 }
 
 __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_split(const SkMlpArgs A) {
-  __shared__ uint4 wq[2 * 4096];  // two quarters
+  __shared__ uint4 ring[3 * SKP_TILE_U4];  // three output tiles of the 256 x 256 layer (96 KB)
+  __shared__ uint4 w3s[2 * 16 * 64];       // layer 3, [hi, lo][16 k-steps][64 lanes] (32 KB)
   __shared__ float b2s[SKP_HIDDEN];
   // (the branch's descriptor is read from the kernel-argument segment by index: one set of scalar registers, not two and a select)
   const SkMlpDev &net = A.net[blockIdx.y];
@@ -565,38 +587,57 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
   SkMlpDraw draw = A.draw;
   draw.enable = blockIdx.y ? 0 : A.draw.enable;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), col = lane & 31, h = lane >> 5;
-  const uint32_t buf0 = SKP_LDS32(wq), buf1 = buf0 + 65536;
-  skp_dma_quarter(net, 0, buf0, wave, lane);
-  if (threadIdx.x < SKP_HIDDEN) b2s[threadIdx.x] = net.b2[threadIdx.x];
+  SKP_STAMP_DECL;
+  SKP_STAMP(0);
+  SKP_RSTAMP(29);
+  uint32_t ob[8];
+  skp_record_load(R, ((long long)blockIdx.x * passes * SKP_WG + wave) * 32 + col, ob);
+  {
+    // what stays in LDS for the whole launch (layer 3, layer 2's bias) and the first two tiles of the ring
+    if (threadIdx.x < SKP_HIDDEN) b2s[threadIdx.x] = net.b2[threadIdx.x];
+    skp_u32x4 t3[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) t3[j] = *(const skp_u32x4 *)(((wave >> 2) ? net.w3l : net.w3) + (wave & 3) * 256 + j * 64 + lane);
+#pragma unroll
+    for (int j = 0; j < 4; j++) *(skp_u32x4 *)(w3s + wave * 256 + j * 64 + lane) = t3[j];
+#pragma unroll
+    for (int tile = 0; tile < 2; tile++) {
+      SkpStage a, b;
+      skp_stage_load(net, tile, wave, lane, 0, a);
+      skp_stage_load(net, tile, wave, lane, 1, b);
+#pragma unroll
+      for (int k = 0; k < 2; k++) skp_stage_store(ring + tile * SKP_TILE_U4 + lane, wave, 0, k, a), skp_stage_store(ring + tile * SKP_TILE_U4 + lane, wave, 1, k, b);
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
   for (int pass = 0; pass < passes; pass++) {
     const long long batch = (long long)blockIdx.x * passes + pass;
     if (batch * SKP_GAMES_PER_WG >= R.n && pass > 0) break;
     const bool more = pass + 1 < passes && (batch + 1) * SKP_GAMES_PER_WG < R.n;  // this workgroup has another batch
     const long long g = (batch * SKP_WG + wave) * 32 + col;
-    skp_bf16x8 x[2];
-    {
-      uint32_t ob[8];
-      skp_record_load(R, g, ob);
-      skp_inputs(R, ob, h, x);
-    }
-    // quarter 0 has landed (requested before the loop / behind the previous batch's stage 4); quarter 1 goes into the other buffer
-    skp_vm_drain();
-    __syncthreads();
-    skp_dma_quarter(net, 1, buf1, wave, lane);
-    // ---- layer 1: (hi + lo) weights x exact inputs, activations split into hi + lo; layer 2's first chain (output tile 0) follows
-    // it k-step by k-step: tile t - 1's two k-steps between the activations of tile t ----
+    // this batch's tile u lives in ring slot (8 pass + u) % 3: rot[u % 3] is this lane's fragment of its k-step 0 (hi)
+    uint4 *rot[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) rot[k] = ring + ((8 * pass + k) % 3) * SKP_TILE_U4 + lane;
+    // ---- layer 1: (hi + lo) weights x exact inputs, the four fragments of tile t + 2 requested while tile t is activated;
+    // layer 2's first chain (output tile 0) follows it k-step by k-step: tile t - 1's two
+    // k-steps between the activations of tile t.  Tile 2 travels into the ring on the side ----
+    skp_bf16x8 x[2], w1f[4], w1n[4];  // [k-step][lo, hi] of the tile whose MFMAs come next / the one after
+#pragma unroll
+    for (int k = 0; k < 4; k++) w1f[k] = skp_frag(((k & 1) ? net.w1 : net.w1l) + (k >> 1) * 64 + lane);
+#pragma unroll
+    for (int k = 0; k < 4; k++) w1n[k] = skp_frag(((k & 1) ? net.w1 : net.w1l) + (2 + (k >> 1)) * 64 + lane);
+    skp_inputs(R, ob, h, x);
+    SKP_STAMP(1 + 14 * (pass > 0));
     skp_bf16x8 h1h[16], h1l[16];
     skp_f32x16 cur = skp_zero();
     {
-      skp_bf16x8 w1f[4];  // [lo, hi of k-step 0, lo, hi of k-step 1]
-#pragma unroll
-      for (int k = 0; k < 4; k++) w1f[k] = skp_frag(((k & 1) ? net.w1 : net.w1l) + (k >> 1) * 64 + lane);
       skp_f32x16 acc = skp_zero();
 #pragma unroll
       for (int k = 0; k < 4; k++) acc = SKP_MFMA(w1f[k], x[k >> 1], acc);
-#pragma unroll
-      for (int k = 0; k < 4; k++) w1f[k] = skp_frag(((k & 1) ? net.w1 : net.w1l) + (2 + (k >> 1)) * 64 + lane);
       SKP_GAP_END;
+      SkpStage st;
 #pragma unroll
       for (int t = 0; t < 8; t++) {
         SkpActS act;
@@ -605,16 +646,19 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
         const int ks0 = 2 * (t - 1), ks1 = ks0 + 1;
 #pragma unroll
         for (int gp = 0; gp < SKP_L1_GAPS; gp++) {
-          if (t < 7 && gp < 4) nxt = SKP_MFMA(w1f[gp], x[gp >> 1], nxt);
+          if (t < 7 && gp < 4) nxt = SKP_MFMA(w1n[gp], x[gp >> 1], nxt);
           if (t < 6 && gp >= 4 && gp < 8)
-            w1f[gp - 4] = skp_frag((((gp - 4) & 1) ? net.w1 : net.w1l) + ((t + 2) * 2 + ((gp - 4) >> 1)) * 64 + lane);
+            w1n[gp - 4] = skp_frag((((gp - 4) & 1) ? net.w1 : net.w1l) + ((t + 2) * 2 + ((gp - 4) >> 1)) * 64 + lane);
           if (t >= 1) {
-            if (gp == 2) c0h = skp_frag(wq + ks0 * 64 + lane), c0l = skp_frag(wq + 1024 + ks0 * 64 + lane);
-            if (gp == 8) c1h = skp_frag(wq + ks1 * 64 + lane), c1l = skp_frag(wq + 1024 + ks1 * 64 + lane);
+            if (gp == 2) c0h = skp_frag(rot[0] + ks0 * 64), c0l = skp_frag(rot[0] + 1024 + ks0 * 64);
+            if (gp == 8) c1h = skp_frag(rot[0] + ks1 * 64), c1l = skp_frag(rot[0] + 1024 + ks1 * 64);
             if (gp >= 6 && gp < 9) cur = SKP_MFMA(gp == 7 ? c0l : c0h, gp == 6 ? h1l[ks0] : h1h[ks0], cur);
             if (gp >= 12 && gp < 15) cur = SKP_MFMA(gp == 13 ? c1l : c1h, gp == 12 ? h1l[ks1] : h1h[ks1], cur);
           }
-          skp_act_split_gap<false, 1, 0>(act, gp, acc, nullptr, h);
+          // tile 2's two halves: requested in tiles 0 / 4 of layer 1, written in tiles 3 / 7
+          if ((t == 0 || t == 4) && gp == 10) skp_stage_load(net, 2, wave, lane, t == 4, st);
+          if ((t == 3 || t == 7) && (gp == 16 || gp == 17)) skp_stage_store(rot[2], wave, t == 7, gp - 16, st);
+          skp_act_split_gap<false, 1, 0>(act, gp, acc, (skp_lds_f32)0, h);
           SKP_GAP_END;
         }
         h1h[2 * t] = skp_frag4((const uint32_t(&)[4])act.hi[0]), h1h[2 * t + 1] = skp_frag4((const uint32_t(&)[4])act.hi[4]);
@@ -623,13 +667,15 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
       }
 #pragma unroll
       for (int ks = 14; ks < 16; ks++) {
-        const skp_bf16x8 ch = skp_frag(wq + ks * 64 + lane), cl = skp_frag(wq + 1024 + ks * 64 + lane);
+        const skp_bf16x8 ch = skp_frag(rot[0] + ks * 64), cl = skp_frag(rot[0] + 1024 + ks * 64);
         cur = SKP_MFMA(ch, h1l[ks], cur);
         cur = SKP_MFMA(cl, h1h[ks], cur);
         cur = SKP_MFMA(ch, h1h[ks], cur);
       }
     }
-    // ---- layers 2 and 3 ----
+    SKP_STAMP(3 + 14 * (pass > 0));
+    // ---- layers 2 and 3.  One barrier per stage: everybody's share of the tile that is read two stages on has been written, and
+    // everybody is through with the slot that the next stage refills ----
     skp_f32x16 acc3;
     {
       const float4 *bp = (const float4 *)(net.b3 + (size_t)lane * 16);
@@ -639,33 +685,41 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
         acc3[4 * q] = b.x, acc3[4 * q + 1] = b.y, acc3[4 * q + 2] = b.z, acc3[4 * q + 3] = b.w;
       }
     }
-    skp_bf16x8 fh[2], fl[2], w3f[4];
     SKP_GAP_END;
-    skp_stage_split<0>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
-    skp_vm_drain();
-    __syncthreads();  // quarter 1 is there, quarter 0's buffer is free
-    skp_dma_quarter(net, 2, buf0, wave, lane);
-    skp_stage_split<1>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
-    skp_stage_split<2>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
-    skp_vm_drain();
     __syncthreads();
-    skp_dma_quarter(net, 3, buf1, wave, lane);
-    skp_stage_split<3>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
-    skp_stage_split<4>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
-    skp_vm_drain();
+    skp_bf16x8 ah = skp_frag(rot[1]), al = skp_frag(rot[1] + 1024);
+    uint32_t bias_off = SKP_LDS32(b2s) + 16 * h;  // (pinned as an LDS offset: through a generic pointer the reads became flat loads,
+    SKP_PIN(bias_off);                             // each waiting for every vector-memory operation in flight)
+    skp_lds_f32 bias_h = (skp_lds_f32)(uintptr_t)bias_off;
+    SKP_STAMP(5 + 14 * (pass > 0));
+    skp_stage_split<0>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
     __syncthreads();
-    if (more) skp_dma_quarter(net, 0, buf0, wave, lane);
-    skp_stage_split<5>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
-    skp_stage_split<6>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
-    skp_stage_split<7>(net, wq, b2s, lane, h, h1h, h1l, cur, acc3, fh, fl, w3f);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; s2++) {
-      acc3 = SKP_MFMA(w3f[2 * s2], fl[s2], acc3);
-      acc3 = SKP_MFMA(w3f[2 * s2 + 1], fh[s2], acc3);
-      acc3 = SKP_MFMA(w3f[2 * s2], fh[s2], acc3);
-    }
+    SKP_STAMP(6 + 14 * (pass > 0));
+    skp_stage_split<1>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
+    __syncthreads();
+    SKP_STAMP(7 + 14 * (pass > 0));
+    skp_stage_split<2>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
+    __syncthreads();
+    SKP_STAMP(8 + 14 * (pass > 0));
+    skp_stage_split<3>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
+    __syncthreads();
+    SKP_STAMP(9 + 14 * (pass > 0));
+    skp_stage_split<4>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
+    __syncthreads();
+    SKP_STAMP(10 + 14 * (pass > 0));
+    skp_stage_split<5>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
+    __syncthreads();
+    SKP_STAMP(11 + 14 * (pass > 0));
+    skp_stage_split<6>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
+    __syncthreads();
+    if (more) skp_record_load(R, ((batch + 1) * SKP_WG + wave) * 32 + col, ob);
+    SKP_STAMP(12 + 14 * (pass > 0));
+    skp_stage_split<7>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
+    SKP_STAMP(13 + 14 * (pass > 0));
     skp_finish(acc3, lane, g, R, net.out_dim, out, draw);
+    SKP_STAMP(14 + 14 * (pass > 0));
   }
+  SKP_RSTAMP(30);
 }
 
 int sk_launch_mlp(const SkMlpDev &a, const SkMlpDev &b, int nets, const SkMlpRecords &r, float *out_a, const SkMlpDraw &draw,

@@ -30,16 +30,19 @@ rows = []
 def seg(a, b, label):
     d = st[:, b] - st[:, a]
     rows.append((label, float(np.median(d)), float(d.min()), float(d.max())))
-seg(0, 1, "pass0 record waited, loads issued")
+seg(0, 1, "pass0 record waited, loads issued (fp32: + first two tiles staged)")
 seg(1, 3, "pass0 layer 1 (+ staging writes)")
-seg(3, 4, "pass0 barrier (weights in LDS)")
-seg(4, 5, "pass0 chain(0)")
+if prec == "bf16":
+    seg(3, 4, "pass0 barrier (weights in LDS)")
+    seg(4, 5, "pass0 chain(0)")
+else:
+    seg(3, 5, "pass0 barrier before stage 0")
 for u in range(8):
     seg(5 + u, 6 + u, "pass0 stage %d (+ wait)" % u)
 seg(13, 14, "pass0 finish (draw / stores)")
 seg(14, 15, "pass1 record waited, loads issued")
 seg(15, 17, "pass1 layer 1")
-seg(17, 19, "pass1 chain(0)")
+seg(17, 19, "pass1 chain(0) / barrier")
 for u in range(8):
     seg(19 + u, 20 + u, "pass1 stage %d" % u)
 seg(27, 28, "pass1 finish")
