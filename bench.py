@@ -294,7 +294,7 @@ def side_model_config(precision, B, N, T, rounds, device):
     out = {"workload": f"{B} x {N}-player games, action-mask model (policy + value net, 256-256 tanh, random weights) picks every action; "
                        f"skyjo_vec_model_rollout: 2 launches per lockstep iteration, rollout columns written",
            "precision": precision, "value": c["steps"] / dt, "unit": "env-steps/s", "ms_per_iteration": 1e3 * dt / (rounds * T),
-           "timed_iterations": rounds * T, "dominant_kernel": "k_mlp_forward_split" if precision == "fp32" else "k_mlp_forward",
+           "timed_iterations": rounds * T, "dominant_kernel": "k_net_split" if precision == "fp32" else "k_net_bf16",
            "dominant_kernel_ms": mlp_ms, "step_kernel_ms": prof["step_ms"] / max(prof["step_launches"], 1),
            "roofline_bound": "mfma", "roofline_achieved_tflops": flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else None,
            "roofline_frac": flops / (mlp_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS if mlp_ms > 0 else None,

@@ -1323,8 +1323,11 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
   if (!REGACC)
     for (int k = 0; k < SK_ACC_KINDS * P.L.N; k++) ACC(k) = 0.0;
   STAMP_DECL;
-  // the tile comes in by LDS-DMA as well (non-temporal: it is read once per launch)
-  dma_record<true>((const uint8_t *)P.state, (uint32_t)((((size_t)tile * P.L.chunks) * SK_TILE + lane) * 16), lds_tile, P.L.chunks);
+  // the tile comes in by LDS-DMA as well (non-temporal: it is read once per launch); a step with caller actions - ONE iteration per
+  // launch, the tile's round trip IS the kernel - takes it through registers instead (EXPERIMENTS round 6: an LDS-DMA piece costs the
+  // issuing wavefront 100 - 180 cycles and lands slowly; config 5's step kernel 11.7 -> 11.1 us)
+  if (!POLICY) tile_load(P, P.state, tile, lane, lp);
+  else dma_record<true>((const uint8_t *)P.state, (uint32_t)((((size_t)tile * P.L.chunks) * SK_TILE + lane) * 16), lds_tile, P.L.chunks);
   if (P.ov_flags & 1u) sk_publish_deals(P, g);  // (while the tile is on its way)
   sk_vm_drain();
   HdrRegs h;

@@ -85,6 +85,38 @@ def test_policy_net_matches_torch(N, B, branch, precision):
     env.close()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_policy_and_value_net_in_one_launch_over_many_ragged_batches(precision):
+    """A launch is ONE round of workgroups: a workgroup keeps the 256 x 256 layer in LDS and walks through several batches of 256
+    games (csrc/skyjo_policy.hip, `passes`).  140 100 two-player games are 548 batches of both nets over 256 compute units - five
+    per workgroup, the last workgroup's fifth beyond the last game, the last batch partly empty - against the float32 module."""
+    import torch
+
+    from skyjo_rl_amd import SkyjoVecEnv
+    from skyjo_rl_amd.action_mask_model import ActionMaskModel, FusedNet
+
+    torch.manual_seed(3)
+    B = 140100
+    env = SkyjoVecEnv(B, num_players=2)
+    env.seed(None, 11)
+    model = ActionMaskModel(obs_dim=env.obs_dim).cuda()
+    pol, val = FusedNet(model.policy, precision=precision), FusedNet(model.value, precision=precision)
+    rec = env.reset()
+    for t in range(3):
+        rec = env.step(env.sample_actions(torch.zeros((B, 26), device="cuda"), rec, seed=2, ticket=t))
+    x = env.split(rec).observations.to(torch.float32)
+    logits = torch.empty((B, 26), device="cuda")
+    values = torch.empty((B, 1), device="cuda")
+    act = pol.act(env, rec, seed=5, ticket=0, logits=logits, value_net=val, values=values)
+    with torch.no_grad():
+        ref, vref = model.policy(x), model.value(x)
+    tol = TOL[precision]
+    assert float((logits - ref).abs().max()) <= tol["max"] and float((values - vref).abs().max()) <= tol["max"]
+    assert torch.equal(pol(rec), logits) and torch.equal(val(rec), values)  # the single-net launches (other `passes`) give the same bits
+    assert bool(env.split(rec).action_mask.gather(1, act.long().unsqueeze(1)).squeeze(1).eq(1).all())
+    pol.close(), val.close(), env.close()
+
+
 def test_fused_policy_loop_plays_legal_games():
     import torch
 
