@@ -341,6 +341,22 @@ int skyjo_vec_mlp_act_value(skyjo_vec *h, const skyjo_vec_mlp *policy, const sky
  * into final_rewards_out double [num_envs][num_players], zeros elsewhere.  One small kernel, no host traffic. */
 int skyjo_vec_episode_ends(skyjo_vec *h, const void *records, double *final_rewards_out, uint8_t *episode_end_out, void *stream);
 
+/* The same consumers for records in an explicit layout (SKYJO_REC_ROW_MAJOR, or SKYJO_REC_TILE_PLANAR: what skyjo_vec_rollout writes with
+ * SKYJO_OPT_RECORD_LAYOUT = tile-planar - piece p of game 64 t + l at block t * 64 * record_bytes + p * 1024 + l * 16 - is read in place,
+ * no skyjo_vec_unpack_tiles pass; n counts games, the last tile's block is complete in memory whatever n).  Same results, bit for
+ * bit, as the row-major calls on the same records (tests/test_gpu_record_layout.py).  value / values_out of ..._act_value_layout
+ * may be NULL (then it is skyjo_vec_mlp_act). */
+int skyjo_vec_mlp_forward_layout(const skyjo_vec_mlp *m, const void *records, int32_t record_bytes, int32_t layout, int64_t n, float *out,
+                                 void *stream);
+int skyjo_vec_mlp_act_value_layout(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, const void *records, int32_t layout,
+                                   int64_t n, uint64_t seed, uint64_t ticket, int32_t no_masking, int32_t *actions_out, float *logp_out,
+                                   float *logits_out, float *values_out, void *stream);
+int skyjo_vec_sample_actions_layout(skyjo_vec *h, const void *records, int32_t layout, const float *logits, int64_t n, uint64_t seed,
+                                    uint64_t ticket, int32_t no_masking, int32_t *actions_out, float *logp_out,
+                                    float *uniform_out, void *stream);
+int skyjo_vec_episode_ends_layout(skyjo_vec *h, const void *records, int32_t layout, double *final_rewards_out, uint8_t *episode_end_out,
+                                  void *stream);
+
 /* skyjo_vec_step that also does what skyjo_vec_episode_ends does, inside the step kernel (no extra launch): the lane that
  * ends an episode writes episode_end_out[game] = 1 and the game's final rewards, every other game 0 / zeros. */
 int skyjo_vec_step_collect(skyjo_vec *h, const int32_t *actions, void *records_out, double *final_rewards_out,

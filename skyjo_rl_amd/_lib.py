@@ -72,6 +72,9 @@ class RolloutBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("records", "actions", "logp", "values", "final_rewards", "episode_end")]
 
 
+# option ids / record layouts of include/skyjo_vec.h
+OPT_RECORD_LAYOUT, REC_ROW_MAJOR, REC_TILE_PLANAR = 6, 0, 1
+
 # name -> (restype, argtypes); this table is also what tests/test_capi_symbols.py checks against the header
 VP, I32, I64, U64, U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_uint32
 SIGNATURES = {
@@ -95,6 +98,10 @@ SIGNATURES = {
     "skyjo_vec_mlp_act": (C.c_int, [VP, VP, VP, I64, U64, U64, I32, VP, VP, VP, VP]),
     "skyjo_vec_mlp_act_value": (C.c_int, [VP, VP, VP, VP, I64, U64, U64, I32, VP, VP, VP, VP, VP]),
     "skyjo_vec_episode_ends": (C.c_int, [VP, VP, VP, VP, VP]),
+    "skyjo_vec_episode_ends_layout": (C.c_int, [VP, VP, I32, VP, VP, VP]),
+    "skyjo_vec_sample_actions_layout": (C.c_int, [VP, VP, I32, VP, I64, U64, U64, I32, VP, VP, VP, VP]),
+    "skyjo_vec_mlp_forward_layout": (C.c_int, [VP, VP, I32, I32, I64, VP, VP]),
+    "skyjo_vec_mlp_act_value_layout": (C.c_int, [VP, VP, VP, VP, I32, I64, U64, U64, I32, VP, VP, VP, VP, VP]),
     "skyjo_vec_step_collect": (C.c_int, [VP, VP, VP, VP, VP, VP]),
     "skyjo_vec_model_rollout": (C.c_int, [VP, VP, VP, I32, U64, U64, I32, C.POINTER(RolloutBuffers), VP]),
     "skyjo_vec_rewards_ptr": (VP, [VP]),

@@ -94,22 +94,29 @@ class FusedNet:
                                                 *[a.ctypes.data_as(C.c_void_p) for a in arrs], C.byref(h)))
         self._h, self._C, self._check = h, C, _lib.check
 
-    def __call__(self, records, out=None):
-        n = records.numel() // records.shape[-1]
+    def __call__(self, records, out=None, planar=False):
+        """Outputs float32 [n, out_dim] for the records' games.  ``planar``: ``records`` is tile-planar ([..., tiles, P, 64, 16], what
+        ``SkyjoVecEnv.rollout`` writes with ``set_record_layout("tile-planar")``), read in place; n = 64 x the number of blocks
+        (the rows beyond ``num_envs`` of a partial last tile are computed from whatever the block holds)."""
+        rb = int(records.shape[-3] * 16) if planar else int(records.shape[-1])
+        n = records.numel() // rb
         if out is None:
             out = torch.empty((n, self.out_dim), dtype=torch.float32, device=records.device)
         C = self._C
-        self._check(self._L.skyjo_vec_mlp_forward(self._h, C.c_void_p(records.data_ptr()), int(records.shape[-1]), n,
-                                                  C.c_void_p(out.data_ptr()),
-                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        from . import _lib
+        self._check(self._L.skyjo_vec_mlp_forward_layout(self._h, C.c_void_p(records.data_ptr()), rb,
+                                                         _lib.REC_TILE_PLANAR if planar else _lib.REC_ROW_MAJOR, n,
+                                                         C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         return out
 
     def act(self, env, records, seed=0, ticket=0, no_masking=False, actions=None, logp=None, logits=None, value_net=None,
-            values=None):
+            values=None, planar=False):
         """Policy branch + masked categorical draw in one launch (``skyjo_vec_mlp_act``): int32 actions for ``env.step``.
         With ``value_net`` (the ``FusedNet`` of the value branch) and ``values`` (float32 [n, 1]) the value estimates of
-        the same records are computed by the same launch (``skyjo_vec_mlp_act_value``)."""
-        n = records.numel() // records.shape[-1]
+        the same records are computed by the same launch (``skyjo_vec_mlp_act_value``).  ``planar``: ``records`` is ONE iteration's
+        tile-planar block of ``env`` ([tiles, P, 64, 16]), read in place; n = env.num_envs."""
+        from . import _lib
+        n = env.num_envs if planar else records.numel() // records.shape[-1]
         if actions is None:
             actions = torch.empty((n,), dtype=torch.int32, device=records.device)
         C = self._C
@@ -117,12 +124,10 @@ class FusedNet:
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         if value_net is not None:
             assert values is not None and values.numel() == n * value_net.out_dim and values.dtype == torch.float32
-            self._check(self._L.skyjo_vec_mlp_act_value(env._h, self._h, value_net._h, vp(records), n, int(seed), int(ticket),
-                                                        1 if no_masking else 0, vp(actions), vp(logp), vp(logits), vp(values),
-                                                        stream))
-        else:
-            self._check(self._L.skyjo_vec_mlp_act(env._h, self._h, vp(records), n, int(seed), int(ticket), 1 if no_masking else 0,
-                                                  vp(actions), vp(logp), vp(logits), stream))
+        self._check(self._L.skyjo_vec_mlp_act_value_layout(env._h, self._h, value_net._h if value_net is not None else None, vp(records),
+                                                           _lib.REC_TILE_PLANAR if planar else _lib.REC_ROW_MAJOR, n, int(seed), int(ticket),
+                                                           1 if no_masking else 0, vp(actions), vp(logp), vp(logits),
+                                                           vp(values) if value_net is not None else None, stream))
         return actions
 
     def close(self):

@@ -1016,18 +1016,25 @@ const double *skyjo_vec_rewards_ptr(const skyjo_vec *h) { return h ? h->P.reward
 const double *skyjo_vec_scores_ptr(const skyjo_vec *h) { return h ? h->P.scores : nullptr; }
 const uint8_t *skyjo_vec_done_ptr(const skyjo_vec *h) { return h ? h->P.done : nullptr; }
 
-int skyjo_vec_sample_actions(skyjo_vec *h, const void *records, const float *logits, int64_t n, uint64_t seed,
-                             uint64_t ticket, int32_t no_masking, int32_t *actions_out, float *logp_out,
-                             float *uniform_out, void *stream) {
+int skyjo_vec_sample_actions_layout(skyjo_vec *h, const void *records, int32_t layout, const float *logits, int64_t n, uint64_t seed,
+                                    uint64_t ticket, int32_t no_masking, int32_t *actions_out, float *logp_out,
+                                    float *uniform_out, void *stream) {
   if (!h || !records || !logits || !actions_out || n < 0) return fail(SKYJO_E_INVALID, "null argument");
+  if (layout != SKYJO_REC_ROW_MAJOR && layout != SKYJO_REC_TILE_PLANAR) return fail(SKYJO_E_INVALID, "layout must be SKYJO_REC_ROW_MAJOR or SKYJO_REC_TILE_PLANAR");
   GUARD(h);
   if (n == 0) return SKYJO_OK;
   const int64_t blocks = (n + SK_SAMPLE_BLOCK - 1) / SK_SAMPLE_BLOCK;
   hipLaunchKernelGGL(k_sample, dim3((unsigned)blocks), dim3(SK_SAMPLE_BLOCK), 0, (hipStream_t)stream, h->P.L,
                      (const uint8_t *)records, logits, (long long)n, seed, ticket, h->P.game_id0, (int)no_masking,
-                     actions_out, logp_out, uniform_out);
+                     actions_out, logp_out, uniform_out, (int)(layout == SKYJO_REC_TILE_PLANAR));
   HIPCHK(hipGetLastError());
   return SKYJO_OK;
+}
+int skyjo_vec_sample_actions(skyjo_vec *h, const void *records, const float *logits, int64_t n, uint64_t seed,
+                             uint64_t ticket, int32_t no_masking, int32_t *actions_out, float *logp_out,
+                             float *uniform_out, void *stream) {
+  return skyjo_vec_sample_actions_layout(h, records, SKYJO_REC_ROW_MAJOR, logits, n, seed, ticket, no_masking, actions_out, logp_out, uniform_out,
+                                         stream);
 }
 
 int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, int32_t precision, const float *w1, const float *b1,
@@ -1131,54 +1138,66 @@ int skyjo_vec_mlp_destroy(skyjo_vec_mlp *m) {
   return SKYJO_OK;
 }
 
-int skyjo_vec_mlp_forward(const skyjo_vec_mlp *m, const void *records, int32_t record_bytes, int64_t n, float *out,
-                          void *stream) {
+int skyjo_vec_mlp_forward_layout(const skyjo_vec_mlp *m, const void *records, int32_t record_bytes, int32_t layout, int64_t n, float *out,
+                                 void *stream) {
   if (!m || !records || !out || n < 0 || record_bytes < 32 || (record_bytes & 15))
     return fail(SKYJO_E_INVALID, "skyjo_vec_mlp_forward: bad argument");
+  if (layout != SKYJO_REC_ROW_MAJOR && layout != SKYJO_REC_TILE_PLANAR) return fail(SKYJO_E_INVALID, "layout must be SKYJO_REC_ROW_MAJOR or SKYJO_REC_TILE_PLANAR");
   if (n == 0) return SKYJO_OK;
   DevGuard guard_(m->device_id);
   SkMlpDraw nodraw{};
-  return launch_mlp(m, m, 1, (const uint8_t *)records, (int)record_bytes, m->obs_dim, n, out, nodraw, nullptr, (hipStream_t)stream);
-  return SKYJO_OK;
+  return launch_mlp(m, m, 1, (const uint8_t *)records, (int)record_bytes, m->obs_dim, n, out, nodraw, nullptr, (hipStream_t)stream, nullptr,
+                    (int)(layout == SKYJO_REC_TILE_PLANAR));
+}
+int skyjo_vec_mlp_forward(const skyjo_vec_mlp *m, const void *records, int32_t record_bytes, int64_t n, float *out,
+                          void *stream) {
+  return skyjo_vec_mlp_forward_layout(m, records, record_bytes, SKYJO_REC_ROW_MAJOR, n, out, stream);
 }
 
-int skyjo_vec_mlp_act(skyjo_vec *h, const skyjo_vec_mlp *m, const void *records, int64_t n, uint64_t seed, uint64_t ticket,
-                      int32_t no_masking, int32_t *actions_out, float *logp_out, float *logits_out, void *stream) {
-  if (!h || !m || !records || !actions_out || n < 0) return fail(SKYJO_E_INVALID, "skyjo_vec_mlp_act: bad argument");
-  GUARD(h);
-  if (m->net.out_dim != SKYJO_NUM_ACTIONS) return fail(SKYJO_E_INVALID, "skyjo_vec_mlp_act needs a net with 26 outputs");
-  if (n == 0) return SKYJO_OK;
-  SkMlpDraw d{};
-  d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = ticket;
-  d.game_id0 = h->P.game_id0, d.actions = actions_out, d.logp = logp_out;
-  return launch_mlp(m, m, 1, (const uint8_t *)records, (int)h->P.L.rec_bytes, m->obs_dim, n, logits_out, d, nullptr, (hipStream_t)stream);
-}
-
-int skyjo_vec_mlp_act_value(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, const void *records, int64_t n,
-                            uint64_t seed, uint64_t ticket, int32_t no_masking, int32_t *actions_out, float *logp_out,
-                            float *logits_out, float *values_out, void *stream) {
-  if (!h || !policy || !value || !records || !actions_out || !values_out || n < 0)
+int skyjo_vec_mlp_act_value_layout(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, const void *records, int32_t layout,
+                                   int64_t n, uint64_t seed, uint64_t ticket, int32_t no_masking, int32_t *actions_out, float *logp_out,
+                                   float *logits_out, float *values_out, void *stream) {
+  if (!h || !policy || !records || !actions_out || n < 0 || (value && !values_out))
     return fail(SKYJO_E_INVALID, "skyjo_vec_mlp_act_value: bad argument");
+  if (layout != SKYJO_REC_ROW_MAJOR && layout != SKYJO_REC_TILE_PLANAR) return fail(SKYJO_E_INVALID, "layout must be SKYJO_REC_ROW_MAJOR or SKYJO_REC_TILE_PLANAR");
   GUARD(h);
   if (policy->net.out_dim != SKYJO_NUM_ACTIONS) return fail(SKYJO_E_INVALID, "the policy net needs 26 outputs");
-  if (policy->obs_dim != value->obs_dim || policy->device_id != value->device_id || policy->device_id != h->cfg.device_id ||
-      policy->net.split != value->net.split)
+  if (value && (policy->obs_dim != value->obs_dim || policy->device_id != value->device_id || policy->device_id != h->cfg.device_id ||
+                policy->net.split != value->net.split))
     return fail(SKYJO_E_INVALID, "policy and value net must share the observation size, the precision and the engine's device");
   if (n == 0) return SKYJO_OK;
   SkMlpDraw d{};
   d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = ticket;
   d.game_id0 = h->P.game_id0, d.actions = actions_out, d.logp = logp_out;
-  return launch_mlp(policy, value, 2, (const uint8_t *)records, (int)h->P.L.rec_bytes, policy->obs_dim, n, logits_out, d, values_out,
-                    (hipStream_t)stream);
+  return launch_mlp(policy, value ? value : policy, value ? 2 : 1, (const uint8_t *)records, (int)h->P.L.rec_bytes, policy->obs_dim, n, logits_out,
+                    d, value ? values_out : nullptr, (hipStream_t)stream, nullptr, (int)(layout == SKYJO_REC_TILE_PLANAR));
+}
+int skyjo_vec_mlp_act(skyjo_vec *h, const skyjo_vec_mlp *m, const void *records, int64_t n, uint64_t seed, uint64_t ticket,
+                      int32_t no_masking, int32_t *actions_out, float *logp_out, float *logits_out, void *stream) {
+  if (!m) return fail(SKYJO_E_INVALID, "skyjo_vec_mlp_act: bad argument");
+  return skyjo_vec_mlp_act_value_layout(h, m, nullptr, records, SKYJO_REC_ROW_MAJOR, n, seed, ticket, no_masking, actions_out, logp_out, logits_out,
+                                        nullptr, stream);
+}
+int skyjo_vec_mlp_act_value(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, const void *records, int64_t n,
+                            uint64_t seed, uint64_t ticket, int32_t no_masking, int32_t *actions_out, float *logp_out,
+                            float *logits_out, float *values_out, void *stream) {
+  if (!value || !values_out) return fail(SKYJO_E_INVALID, "skyjo_vec_mlp_act_value: bad argument");
+  return skyjo_vec_mlp_act_value_layout(h, policy, value, records, SKYJO_REC_ROW_MAJOR, n, seed, ticket, no_masking, actions_out, logp_out,
+                                        logits_out, values_out, stream);
 }
 
-int skyjo_vec_episode_ends(skyjo_vec *h, const void *records, double *final_rewards_out, uint8_t *episode_end_out, void *stream) {
+int skyjo_vec_episode_ends_layout(skyjo_vec *h, const void *records, int32_t layout, double *final_rewards_out, uint8_t *episode_end_out,
+                                  void *stream) {
   if (!h || !records || !final_rewards_out || !episode_end_out) return fail(SKYJO_E_INVALID, "null argument");
+  if (layout != SKYJO_REC_ROW_MAJOR && layout != SKYJO_REC_TILE_PLANAR) return fail(SKYJO_E_INVALID, "layout must be SKYJO_REC_ROW_MAJOR or SKYJO_REC_TILE_PLANAR");
   GUARD(h);
   hipLaunchKernelGGL(k_episode_ends, dim3((h->P.B + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->P, (const uint8_t *)records,
-                     final_rewards_out, episode_end_out);
+                     final_rewards_out, episode_end_out, (int)(layout == SKYJO_REC_TILE_PLANAR));
   HIPCHK(hipGetLastError());
   return SKYJO_OK;
+}
+int skyjo_vec_episode_ends(skyjo_vec *h, const void *records, double *final_rewards_out, uint8_t *episode_end_out, void *stream) {
+  return skyjo_vec_episode_ends_layout(h, records, SKYJO_REC_ROW_MAJOR, final_rewards_out, episode_end_out, stream);
 }
 
 int skyjo_vec_get_counters(skyjo_vec *h, skyjo_vec_counters *out, void *stream) {

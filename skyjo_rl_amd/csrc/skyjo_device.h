@@ -2588,10 +2588,15 @@ __global__ void k_reduce_stats(SkParams P) {
 // stretch that is copied to LDS with coalesced 16-byte loads; a lane then walks its own row (stride 26 words:
 // two lanes per bank).  The mask bytes come straight out of the engine's records.
 // ------------------------------------------------------------------------------------------
+// Byte k of record r in either layout.  `planar`: the records lie tile-planar
+// (SKYJO_REC_TILE_PLANAR: byte k of record r at  (r / 64) * 64 * rec_bytes + (k / 16) * 1024 + (r % 64) * 16 + k % 16).
+__device__ __forceinline__ const uint8_t *sk_rec_byte(const uint8_t *rec, long long r, int k, int rec_bytes, int planar) {
+  return planar ? rec + (r >> 6) * (64LL * rec_bytes) + (long long)(k >> 4) * 1024 + (r & 63) * 16 + (k & 15) : rec + r * rec_bytes + k;
+}
 #define SK_SAMPLE_BLOCK 256
 __global__ __launch_bounds__(SK_SAMPLE_BLOCK) void k_sample(SkLayout L, const uint8_t *rec, const float *logits, long long n,
                                                             uint64_t seed, uint64_t ticket, uint64_t game_id0, int no_masking,
-                                                            int32_t *actions, float *logp, float *uniform) {
+                                                            int32_t *actions, float *logp, float *uniform, int planar) {
   __shared__ float rows[SK_SAMPLE_BLOCK * SKYJO_NUM_ACTIONS];
   const long long g0 = (long long)blockIdx.x * SK_SAMPLE_BLOCK;
   const int nb = (int)(n - g0 < SK_SAMPLE_BLOCK ? n - g0 : SK_SAMPLE_BLOCK);
@@ -2608,10 +2613,9 @@ __global__ __launch_bounds__(SK_SAMPLE_BLOCK) void k_sample(SkLayout L, const ui
   __syncthreads();
   if ((int)threadIdx.x >= nb) return;
   const long long g = g0 + threadIdx.x;
-  const uint8_t *r = rec + g * L.rec_bytes + L.Dp;  // 26 mask bytes, 4-byte aligned
-  uint32_t mw[7];
+  uint32_t mw[7];  // 26 mask bytes from offset Dp (4-byte aligned: a word never straddles two 16-byte pieces)
 #pragma unroll
-  for (int k = 0; k < 7; k++) mw[k] = ((const uint32_t *)r)[k];
+  for (int k = 0; k < 7; k++) mw[k] = *(const uint32_t *)sk_rec_byte(rec, g, L.Dp + 4 * k, L.rec_bytes, planar);
   const float *row = rows + threadIdx.x * SKYJO_NUM_ACTIONS;
   float lp_ = 0.f, u_ = 0.f;
   actions[g] = sk_draw_action(row, mw, no_masking, seed, ticket, game_id0 + (uint64_t)g, logp ? &lp_ : nullptr, &u_);
@@ -2622,22 +2626,18 @@ __global__ __launch_bounds__(SK_SAMPLE_BLOCK) void k_sample(SkLayout L, const ui
 // Rollout collection: from the records a step has just written, mark the games whose episode ended in that
 // step and copy their final rewards (skyjo_env.py:293-312) - zeros elsewhere.  (skyjo_vec_step_collect has the step kernel
 // do the same on its way: no extra launch.)
-__global__ void k_episode_ends(SkParams P, const uint8_t *rec, double *rew_out, uint8_t *end_out) {
+__global__ void k_episode_ends(SkParams P, const uint8_t *rec, double *rew_out, uint8_t *end_out, int planar) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= P.B) return;
-  const uint8_t *meta = rec + (size_t)g * P.L.rec_bytes + P.L.Dp + 26;  // agent, phase, done, status
+  const uint8_t *meta = sk_rec_byte(rec, g, P.L.Dp + 26, P.L.rec_bytes, planar);  // agent, phase, done, status (one 4-byte word)
   // done, and the step that wrote the record applied (or refused) an action: byte D is -1 for a game that was re-dealt,
   // already over or left alone (SKYJO_ACTION_SKIP) - none of those ends an episode (again)
-  const bool end = meta[2] != 0 && (int8_t)rec[(size_t)g * P.L.rec_bytes + P.L.D] != -1;
+  const bool end = meta[2] != 0 && (int8_t)*sk_rec_byte(rec, g, P.L.D, P.L.rec_bytes, planar) != -1;
   end_out[g] = end ? 1 : 0;
   for (int p = 0; p < P.L.N; p++) rew_out[(size_t)g * P.L.N + p] = end ? P.rewards[(size_t)g * P.L.N + p] : 0.0;
 }
 
-// records -> the reference's dense arrays (obs int8[n][D], mask int8[n][26], ...).  `planar`: the records lie tile-planar
-// (SKYJO_REC_TILE_PLANAR: byte k of record r at  (r / 64) * 64 * rec_bytes + (k / 16) * 1024 + (r % 64) * 16 + k % 16).
-__device__ __forceinline__ const uint8_t *sk_rec_byte(const uint8_t *rec, long long r, int k, int rec_bytes, int planar) {
-  return planar ? rec + (r >> 6) * (64LL * rec_bytes) + (long long)(k >> 4) * 1024 + (r & 63) * 16 + (k & 15) : rec + r * rec_bytes + k;
-}
+// records -> the reference's dense arrays (obs int8[n][D], mask int8[n][26], ...) from either layout
 __global__ void k_unpack(SkLayout L, const uint8_t *rec, long long n, int8_t *obs, int8_t *mask, uint8_t *agent,
                          uint8_t *phase, uint8_t *done, uint8_t *status, int planar) {
   const long long total = n * (long long)(L.D + 26);

@@ -120,9 +120,17 @@ class SkyjoVecEnv:
 
     def set_record_layout(self, layout):
         """'row-major' (default) or 'tile-planar' (include/skyjo_vec.h: SKYJO_OPT_RECORD_LAYOUT): how ``rollout`` lays out its
-        records.  Tile-planar records come as ``new_planar_records(iters)`` = uint8 [iters, tiles, record_bytes / 16, 64, 16]."""
-        _lib.check(self._L.skyjo_vec_set_option(self._h, 6, {"row-major": 0, "tile-planar": 1}[layout]))
-        self.record_layout = layout
+        records.  Tile-planar records come as ``new_planar_records(iters)`` = uint8 [iters, tiles, record_bytes / 16, 64, 16];
+        ``FusedNet`` / ``sample_actions`` / ``episode_ends`` read them in place (``planar=True``)."""
+        _lib.check(self._L.skyjo_vec_set_option(self._h, _lib.OPT_RECORD_LAYOUT,
+                                                {"row-major": _lib.REC_ROW_MAJOR, "tile-planar": _lib.REC_TILE_PLANAR}[layout]))
+
+    @property
+    def record_layout(self):
+        """The layout ``rollout`` writes, as the engine has it (SKYJO_OPT_RECORD_LAYOUT)."""
+        v = C.c_int64()
+        _lib.check(self._L.skyjo_vec_get_option(self._h, _lib.OPT_RECORD_LAYOUT, C.byref(v)))
+        return "tile-planar" if v.value == _lib.REC_TILE_PLANAR else "row-major"
 
     def new_planar_records(self, iters):
         return self._torch().empty((iters, self.tiles, self.record_bytes // 16, 64, 16), dtype=self._torch().uint8, device=self._dev())
@@ -195,7 +203,8 @@ class SkyjoVecEnv:
         rp = C.c_void_p(records.data_ptr()) if records is not None else None
         ap = C.c_void_p(actions.data_ptr()) if actions is not None else None
         if records is not None:
-            per_it = self.tiles * 64 if getattr(self, "record_layout", "row-major") == "tile-planar" else self.num_envs
+            planar = self.record_layout == "tile-planar"
+            per_it = self.tiles * 64 if planar else self.num_envs
             assert records.is_contiguous() and records.numel() == iters * per_it * self.record_bytes
         if actions is not None:
             assert actions.is_contiguous() and actions.numel() == iters * self.num_envs
@@ -217,21 +226,37 @@ class SkyjoVecEnv:
                                             C.c_void_p(mask.data_ptr()), None, None, None, None, self._stream()))
         return obs, mask
 
-    def sample_actions(self, logits, records, seed=0, ticket=0, no_masking=False, actions=None, logp=None, uniform=None):
+    def sample_actions(self, logits, records, seed=0, ticket=0, no_masking=False, actions=None, logp=None, uniform=None, planar=False):
         """Masked categorical draw of config 5 (rlskyjo/models/action_mask_model.py:58-74 + the sampling RLlib does on
         the masked logits) fused on the GPU: ``logits`` float32 [n, 26]; the action mask is read in place from
-        ``records``.  Returns int32 actions; ``logp`` / ``uniform`` (float32 [n]) are filled when given."""
+        ``records`` (``planar``: one iteration's tile-planar block [tiles, P, 64, 16], n = num_envs).  Returns int32 actions;
+        ``logp`` / ``uniform`` (float32 [n]) are filled when given."""
         torch = self._torch()
-        n = records.numel() // self.record_bytes
+        n = self.num_envs if planar else records.numel() // self.record_bytes
+        assert not planar or records.numel() == self.tiles * 64 * self.record_bytes
         assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.numel() == n * 26
         assert records.is_contiguous()
         if actions is None:
             actions = torch.empty((n,), dtype=torch.int32, device=self._dev())
         vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        _lib.check(self._L.skyjo_vec_sample_actions(self._h, vp(records), vp(logits), n, int(seed), int(ticket),
-                                                    1 if no_masking else 0, vp(actions), vp(logp), vp(uniform),
-                                                    self._stream()))
+        _lib.check(self._L.skyjo_vec_sample_actions_layout(self._h, vp(records), _lib.REC_TILE_PLANAR if planar else _lib.REC_ROW_MAJOR,
+                                                           vp(logits), n, int(seed), int(ticket), 1 if no_masking else 0, vp(actions),
+                                                           vp(logp), vp(uniform), self._stream()))
         return actions
+
+    def episode_ends(self, records, final_rewards=None, episode_end=None, planar=False):
+        """For the records a step has just written: ``episode_end`` uint8 [num_envs] (1 where that step ended the episode) and
+        ``final_rewards`` float64 [num_envs, num_players] (skyjo_env.py:293-312; zeros elsewhere) - skyjo_vec_episode_ends."""
+        torch = self._torch()
+        if final_rewards is None:
+            final_rewards = torch.empty((self.num_envs, self.num_players), dtype=torch.float64, device=self._dev())
+        if episode_end is None:
+            episode_end = torch.empty((self.num_envs,), dtype=torch.uint8, device=self._dev())
+        assert records.is_contiguous() and records.numel() == (self.tiles * 64 if planar else self.num_envs) * self.record_bytes
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(self._L.skyjo_vec_episode_ends_layout(self._h, vp(records), _lib.REC_TILE_PLANAR if planar else _lib.REC_ROW_MAJOR,
+                                                         vp(final_rewards), vp(episode_end), self._stream()))
+        return final_rewards, episode_end
 
     def rewards_tensor(self):
         torch = self._torch()

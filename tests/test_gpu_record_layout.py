@@ -77,3 +77,48 @@ def test_the_layout_option_is_refused_where_the_kernel_does_not_exist():
     e.set_record_layout("row-major")
     e.rollout(8, records=e.new_records(8))
     e.close()
+
+
+@pytest.mark.parametrize("B,N,precision", [(32768, 4, "bf16"), (40010, 3, "fp32"), (4096, 2, "fp32")])
+def test_the_consumers_read_tile_planar_records_in_place(B, N, precision):
+    """the policy / value net (its observation bytes and, for the draw in its epilogue, the mask words), the masked
+    draw on given logits and the episode-end columns take the tile-planar records of a fused rollout as they lie
+    (skyjo_vec_*_layout, SKYJO_REC_TILE_PLANAR) - the same bits as from the row-major copy of the same records, no unpack pass."""
+    import torch
+    from skyjo_rl_amd import SkyjoVecEnv
+    from skyjo_rl_amd.action_mask_model import ActionMaskModel, FusedNet
+
+    torch.manual_seed(5)
+    env = SkyjoVecEnv(B, num_players=N, auto_reset=True)
+    assert env.dealing_form() == "one kernel"
+    env.set_record_layout("tile-planar")
+    assert env.record_layout == "tile-planar"
+    env.seed(None, 23)
+    K = env.deal_interval()
+    rp = env.new_planar_records(K)
+    rp.zero_()
+    model = ActionMaskModel(obs_dim=env.obs_dim).cuda()
+    pol, val = FusedNet(model.policy, precision=precision), FusedNet(model.value, precision=precision)
+    ends = 0
+    for launch in range(3):
+        env.rollout(K, policy_seed=9, records=rp)
+        rows = env.rows_from_planar(rp).contiguous()
+        for t in (0, K // 2, K - 1):
+            out = {}
+            for planar, rec in ((False, rows[t]), (True, rp[t])):
+                a = torch.empty(B, dtype=torch.int32, device="cuda")
+                lp, lg, v = torch.empty(B, device="cuda"), torch.empty((B, 26), device="cuda"), torch.empty((B, 1), device="cuda")
+                pol.act(env, rec, seed=4, ticket=7 * launch + t, actions=a, logp=lp, logits=lg, value_net=val, values=v, planar=planar)
+                a1 = pol.act(env, rec, seed=4, ticket=7 * launch + t, planar=planar)  # the policy branch alone
+                u = torch.empty(B, device="cuda")
+                a2 = env.sample_actions(lg, rec, seed=4, ticket=7 * launch + t, uniform=u, planar=planar)
+                fr, ee = env.episode_ends(rec, planar=planar)
+                fwd = val(rec, planar=planar)
+                out[planar] = (a, lp, lg, v, a1, a2, u, fr, ee, fwd[:B])
+            for x, y in zip(out[False], out[True]):
+                assert torch.equal(x, y)
+            a, _, _, v, a1, a2, _, _, ee, fwd = out[True]
+            assert torch.equal(a, a1) and torch.equal(a, a2) and torch.equal(v, fwd)
+            ends += int(ee.sum())
+    assert ends > 0  # (some of the sampled iterations ended episodes: the columns are not trivially equal)
+    pol.close(), val.close(), env.close()
