@@ -65,7 +65,11 @@ SETTLE = int(os.environ.get("SKYJO_BENCH_SETTLE", "100"))  # launches between se
 REFERENCE_STEPS_PER_S_1_CORE = 8.3e3
 REFERENCE_STEPS_PER_S_8_CORES = 52.8e3
 TRAFFIC_PROFILE = os.path.join("profiles", "r5_hbm_traffic.json")  # rocprofv3 PMC passes of this very launch shape (tools/refresh_profiles.sh)
-KERNEL_SOURCES = ("skyjo_rl_amd/csrc/skyjo_device.h", "skyjo_rl_amd/csrc/skyjo_capi.hip", "skyjo_rl_amd/csrc/skyjo_layout.h")
+# (the environment's translation unit: skyjo_device.h and its parts; the policy net's unit - skyjo_policy.* - has nothing to do with k_cycle's traffic)
+KERNEL_SOURCES = ("skyjo_rl_amd/csrc/skyjo_device.h", "skyjo_rl_amd/csrc/skyjo_rng.h", "skyjo_rl_amd/csrc/skyjo_transition.h",
+                  "skyjo_rl_amd/csrc/skyjo_record.h", "skyjo_rl_amd/csrc/skyjo_step.h", "skyjo_rl_amd/csrc/skyjo_deal.h",
+                  "skyjo_rl_amd/csrc/skyjo_cycle.h", "skyjo_rl_amd/csrc/skyjo_callers.h", "skyjo_rl_amd/csrc/skyjo_draw.h",
+                  "skyjo_rl_amd/csrc/skyjo_capi.hip", "skyjo_rl_amd/csrc/skyjo_layout.h")
 
 
 def _code_only(text):
@@ -373,7 +377,9 @@ def main():
                          f"(SKYJO_BENCH_SHARED_GPU=1 allows it as a REHEARSAL of the launch path: gloo carries the statistics record.)\n")
         sys.exit(3)
     device = local_rank % ndev
-    if world > 1:
+    # (a process group also for ONE rank when a launcher set the rendezvous up - tools/scale_run.sh 1: the N = 1 point of the scaling
+    # table goes through the same RCCL all-gather as the others)
+    if world > 1 or ("WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ):
         if shared_gpu:
             dist.init_process_group("gloo")
         else:
@@ -442,7 +448,7 @@ def main():
         # a silent single-rank fallback must be impossible: the gathered matrix has one row per rank, every row a full shard
         assert per_rank.shape[0] == world, f"gathered {per_rank.shape[0]} statistics records for {world} ranks"
         assert all(per_rank[r, 0] + per_rank[r, 3] == args.steps * CHUNK * B for r in range(world)), "a rank's steps + resets are not its shard's"
-        if world > 1:
+        if dist.is_initialized():
             t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             t_max = float(t.item())
@@ -487,7 +493,7 @@ def main():
             scaling_note = f"BASELINE configs[3]: 32 768 games per GPU ({world * B} in total; 262 144 at --gpus 8)"
         else:
             scaling_note = f"weak: {B} games per GPU ({world * B} in total)"
-        backend = dist.get_backend() if world > 1 else "none (single rank)"
+        backend = dist.get_backend() if dist.is_initialized() else "none (single rank)"
         try:
             nccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())  # RCCL's version on ROCm
         except Exception as e:  # (reported, not needed by a single rank)

@@ -243,7 +243,7 @@ int skyjo_vec_debug_stamps(skyjo_vec *h, uint64_t *out16_host);
 int skyjo_vec_debug_trace(skyjo_vec *h, uint64_t *out_host);
 
 /* Tunables.  SKYJO_OPT_DEAL_INTERVAL: lockstep iterations (steps or rollout iterations) between two runs of the
- * dealing kernel (1..1024; environment override SKYJO_DEAL_INTERVAL).  Unless it is set, the engine starts at 88 (three
+ * dealing kernel (1..1024).  Unless it is set, the engine starts at 88 (three
  * and more players) or 64 - 80 or 56 with the dealing kernel beside the step kernel - and adapts: every dealing run reports how many banks it found empty, any empty bank shortens
  * the interval, a long calm stretch lengthens it again - so it settles below the episode length of the policy in use.  Every game owns a bank of three
  * pre-dealt episodes and a dealing run adds at most one per game; a finished game whose bank is empty deals in
@@ -263,7 +263,7 @@ int skyjo_vec_debug_trace(skyjo_vec *h, uint64_t *out_host);
  *      (a full chip of four-player games: form 0 there); the fused rollout only - other calls deal
  *      as in form 0;
  *   1  "beside the step kernel" in whichever of the two forms the engine prefers.
- * skyjo_vec_get_option returns 0, 2 or 3.  Environment overrides: SKYJO_OVERLAP (0 / 1), SKYJO_MERGED (0 / 1: prefer form 3). */
+ * skyjo_vec_get_option returns 0, 2 or 3. */
 #define SKYJO_OPT_OVERLAP 2
 /* Fault injection for the tests (never needed in production): SKYJO_OPT_DEBUG_SPIN_LOG2 - a step kernel that has to wait
  * for an overlapped dealing kernel gives up after 2^value polls (default 22) and raises the sticky device error that
@@ -287,6 +287,19 @@ int skyjo_vec_debug_trace(skyjo_vec *h, uint64_t *out_host);
 #define SKYJO_OPT_RECORD_LAYOUT 6
 #define SKYJO_REC_ROW_MAJOR 0
 #define SKYJO_REC_TILE_PLANAR 1
+/* The older forms of a dealing run, kept for the engines the one-kernel form does not cover and selectable so that the parity tests
+ * can hold them against the oracle (results never depend on them):
+ *   SKYJO_OPT_INLINE_WORK_LIST 1: an in-line run uses the k_scan + work-list form (default 0: the dealing kernel scans the banks itself);
+ *   SKYJO_OPT_UNPIPELINED      1: a run beside the step kernel uses the k_scan / k_publish form, whose caller's stream waits for every
+ *                                 run (default 0: the step kernel plans and publishes the runs itself).
+ * SKYJO_OPT_CYCLE_S (before skyjo_vec_seed): step - and dealing - wavefronts per workgroup of the one-kernel form, 1 .. 4; 0 = the
+ * batch's share of tiles per compute unit (the default).  SKYJO_OPT_MAX_CYCLES_PER_LAUNCH: dealing cycles ONE launch of
+ * skyjo_vec_rollout may span, 1 .. 16 (default 16).  The shipped library reads no environment variable; the measurement switches of
+ * tools/dev/README.md exist in -DSK_DIAG builds only. */
+#define SKYJO_OPT_INLINE_WORK_LIST 7
+#define SKYJO_OPT_UNPIPELINED 8
+#define SKYJO_OPT_CYCLE_S 9
+#define SKYJO_OPT_MAX_CYCLES_PER_LAUNCH 10
 int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value);
 int skyjo_vec_get_option(const skyjo_vec *h, int option, int64_t *value_out);
 

@@ -6,8 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-HEADERS = [os.path.join(CSRC, h) for h in ("skyjo_device.h", "skyjo_layout.h", "skyjo_draw.h", "skyjo_policy.h")] + [
-    os.path.join(ROOT, "include", "skyjo_vec.h")]
+HEADERS = sorted(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")) + [os.path.join(ROOT, "include", "skyjo_vec.h")]
 # Two translation units, each with the instruction scheduler that suits it (EXPERIMENTS.md round 5 #11, round 6): the
 # environment kernels gain 1 - 2 % under max-ilp, the policy net's hand-placed MFMA gaps want the default strategy.
 UNITS = [("skyjo_capi", os.path.join(CSRC, "skyjo_capi.hip"), ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]),

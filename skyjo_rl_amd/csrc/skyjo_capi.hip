@@ -14,6 +14,14 @@
 #include "skyjo_device.h"
 #include "skyjo_policy.h"
 
+// Measurement switches (environment variables: tools/dev/README.md) exist in -DSK_DIAG builds only; the shipped library reads no
+// environment variable at all - what a caller or a test may choose is an option of skyjo_vec_set_option.
+#ifdef SK_DIAG
+static const char *sk_diag_env(const char *name) { return getenv(name); }
+#else
+static inline const char *sk_diag_env(const char *) { return nullptr; }
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -130,6 +138,9 @@ struct skyjo_vec {
   uint8_t *hm_mask_d = nullptr, *hm_records_d = nullptr, *hm_raw_d = nullptr;
   int raw_stride = 0;
   uint32_t host_seq = 0;  // sequence number of the last host-style step of a single-tile engine (see skyjo_vec_step_host)
+  uint32_t cycle_seq = 0;   // k_cycle launches so far: launch L counts empty banks into bank_empty[L & 1] and reports the other word
+  int ncu = 256;            // compute units of the device (k_cycle's workgroup sizing)
+  int max_cycles = 0;       // SKYJO_OPT_MAX_CYCLES_PER_LAUNCH (0: the ABI's maximum, kMaxCyclesPerLaunch)
   bool rec_planar = false;  // SKYJO_OPT_RECORD_LAYOUT: skyjo_vec_rollout writes its records tile-planar (one-kernel form, indirect observation)
   bool no_bank = false;  // SKYJO_OPT_NO_BANK: no pre-dealt episodes, every deal is made in place from the stream's position
   // lazily allocated scratch for the *_host conveniences
@@ -219,7 +230,7 @@ int prof_events(skyjo_vec *h, int kernel, hipEvent_t *a, hipEvent_t *b) {
 }
 
 // Make the episodes of the dealing launch that may still be running available (k_publish on the caller's stream).
-static int launch_deal_kernel(skyjo_vec *h, hipStream_t ds, int mode);
+static int launch_deal_kernel(skyjo_vec *h, hipStream_t ds, int mode, int be_read = -1);
 // k_cycle form: a run that was planned but whose carrying launch never came (the caller went on with another kind of call) is
 // dealt here, by the dealing kernel alone on the caller's stream.
 int flush_cycle_deal(skyjo_vec *h, hipStream_t s) {
@@ -227,7 +238,7 @@ int flush_cycle_deal(skyjo_vec *h, hipStream_t s) {
   const uint32_t keep = h->P.deal_tag;
   h->P.deal_tag = h->cycle_deal_tag;
   h->cycle_deal_tag = 0;
-  const int rc = launch_deal_kernel(h, s, 3);
+  const int rc = launch_deal_kernel(h, s, 3, (int)((h->cycle_seq - 1u) & 1u));  // (the word the k_cycle launch that planned it counted into)
   h->P.deal_tag = keep;
   return rc;
 }
@@ -253,9 +264,10 @@ int publish_deals(skyjo_vec *h, hipStream_t s) {
 
 // mode: 0 = work list, beside the step kernel (k_publish follows); 1 = work list, in line; 2 = in line, lane = game, own
 // scan; 3 = beside the step kernel, lane = game, planned by the step kernel (sk_plan_deals)
-int launch_deal_kernel(skyjo_vec *h, hipStream_t ds, int mode) {
+int launch_deal_kernel(skyjo_vec *h, hipStream_t ds, int mode, int be_read) {
   hipEvent_t e0, e1;
   int rc;
+  h->P.be_read = be_read >= 0 ? (uint32_t)be_read : (h->P.deal_tag & 1u);  // (two-stream form: the run's own parity, as the step kernel that planned it counted)
   if ((rc = prof_events(h, 2, &e0, &e1))) return rc;
   // fixed player counts deal from a byte deck per lane; the generic kernel needs the tile + ring
   const uint32_t lds_compact = SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE),  // decks + MtChunkStream's staging rows
@@ -343,6 +355,7 @@ static bool piped_mode(const skyjo_vec *h) { return ((h->overlap && h->piped) ||
 static void plan_cycle(skyjo_vec *h) {
   next_deal_tag(h, false);
   h->P.plan_new_tag = h->deal_tag;
+  h->P.be_add = h->deal_tag & 1u;  // (a k_cycle launch overrides this with its launch parity: launch_step)
   h->P.ov_flags |= 2u;
 }
 int start_deals_piped(skyjo_vec *h, hipStream_t s) {
@@ -390,7 +403,9 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
       lds_total = (size_t)h->cycle_s * (lds_step_region + lds_deal) + 32;
     }
     if (no_defer) lds_deal |= 1u << 29;
-    if (const char *e = getenv("SKYJO_CYCLE_SPLIT")) lds_deal |= (uint32_t)(atoi(e) & 3) << 30;  // diagnostic: 1 = roles by SIMD parity, 2 = by SIMD pair
+    if (const char *e = sk_diag_env("SKYJO_CYCLE_SPLIT")) lds_deal |= (uint32_t)(atoi(e) & 3) << 30;  // diagnostic: 1 = roles by SIMD parity, 2 = by SIMD pair
+    h->P.be_add = h->cycle_seq & 1u, h->P.be_read = (h->cycle_seq & 1u) ^ 1u;
+    h->cycle_seq++;
     const int S = h->cycle_s;
     dim3 cgrid((h->P.tiles + S - 1) / S), cblock(2 * S * SK_TILE);
 #define LAUNCHC(I, NP, PL)                                                                                                                 \
@@ -468,6 +483,59 @@ int launch_mlp(const skyjo_vec_mlp *ma, const skyjo_vec_mlp *mb, int nets, const
   return SKYJO_OK;
 }
 
+// (Re)sizes the one-kernel form for this engine: called by skyjo_vec_create and by SKYJO_OPT_CYCLE_S.
+static void configure_cycle(skyjo_vec *h, int s_override) {
+  // k_cycle: S step + S dealing wavefronts per workgroup, S = what spreads the batch over the 256 CUs (1 .. 4); their LDS
+    // regions and the claim words must fit one CU's 160 KB
+    const int ncu = h->ncu;
+    const SkParams &P = h->P;
+    const bool fixed_n = P.L.N >= 2 && P.L.N <= 4;
+    int S = (P.tiles + ncu - 1) / ncu;
+    S = S < 1 ? 1 : (S > SK_CYCLE_MAX_S ? SK_CYCLE_MAX_S : S);
+    if (s_override >= 1 && s_override <= SK_CYCLE_MAX_S) S = s_override;  // (SKYJO_OPT_CYCLE_S: fewer / more wavefronts per workgroup than the batch's share)
+    const int natural_s = S;
+    const size_t deal_region = (size_t)SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE);
+    size_t per_s = h->lds_rollout + deal_region;
+    h->lds_cycle_step = h->lds_rollout, h->cycle_no_defer = false;
+    if ((size_t)S * per_s + 32 > 160 * 1024 && (size_t)S * (h->lds_step + deal_region) + 32 <= 160 * 1024 && P.L.N <= 3 &&
+        !sk_diag_env("SKYJO_CYCLE_DEFER_ONLY")) {
+      // the direct observation of three players on a full chip: the CU's share of tiles fits without the card chunks of the deferred
+      // scoring (the games are then scored in the iteration they end: a slower step, but one round of workgroups - 31.0 against 23.5
+      // x 10^9 in line; four players, where scoring on the spot costs more: 22.5 against 30.1 - they stay in line)
+      per_s = h->lds_step + deal_region;
+      h->lds_cycle_step = h->lds_step, h->cycle_no_defer = true;
+    }
+    while (S > 1 && (size_t)S * per_s + 32 > 160 * 1024) S--;  // (fewer wavefronts per workgroup, more workgroups)
+    const size_t need = (size_t)S * per_s + 32;
+    const bool fits = fixed_n && need <= 160 * 1024 && !sk_diag_env("SKYJO_LDS_PAD");
+    h->lds_cycle = need, h->cycle_s = S;
+    h->merged_capable = fits;
+    if (fits) {
+      const void *fn = P.L.indirect ? (P.L.N == 2 ? (const void *)k_cycle<true, 2, false> : P.L.N == 3 ? (const void *)k_cycle<true, 3, false> : (const void *)k_cycle<true, 4, false>)
+                                    : (P.L.N == 2 ? (const void *)k_cycle<false, 2, false> : P.L.N == 3 ? (const void *)k_cycle<false, 3, false> : (const void *)k_cycle<false, 4, false>);
+      const void *fnp = P.L.indirect ? (P.L.N == 2 ? (const void *)k_cycle<true, 2, true> : P.L.N == 3 ? (const void *)k_cycle<true, 3, true> : (const void *)k_cycle<true, 4, true>)
+                                     : (P.L.N == 2 ? (const void *)k_cycle<false, 2, true> : P.L.N == 3 ? (const void *)k_cycle<false, 3, true> : (const void *)k_cycle<false, 4, true>);
+      // (the attribute belongs to the function, not to the handle: always the whole CU, so that engines of different batch sizes -
+      // different S - can live side by side in one process)
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+          (fnp && hipFuncSetAttribute(fnp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)) {
+        (void)hipGetLastError();
+        h->merged_capable = false;
+      }
+    }
+    // Default: the one-kernel form wherever it fits (measured at 4 096 .. 65 536 games and two to four players: + 9 .. 32 % over the
+    // two-stream form, + 18 .. 57 % over dealing in line, EXPERIMENTS.md round 4); SKYJO_MERGED=0 falls back to the older forms.
+    // (Batches beyond four tiles per CU run in two or more rounds of workgroups - a workgroup's LDS fills its CU: 98 304 x 3 29.1
+    // against 23.8 in line, 131 072 x 3 34.0 against 21.0; counter-based deals 37.5 / 49.4 against 39.6 / 32.5: the one-kernel
+    // form still wins everywhere but at one and a half rounds of counter-based deals.  Not so where the LDS - not the batch - makes
+    // the workgroups smaller than a CU's share of the tiles, i.e. a full chip of four-player games or of the direct observation: S = 3,
+    // 342 workgroups in one and a third rounds, 25.5 against 30.0 and 17.5 against 23.6 in line.)
+    h->prefer_merged = S == natural_s;
+    if (const char *e = sk_diag_env("SKYJO_MERGED")) h->prefer_merged = atoi(e) != 0;
+    h->merged = h->merged_capable && h->prefer_merged && !sk_diag_env("SKYJO_OVERLAP");
+    if (h->merged) h->overlap = false;  // (no second stream in this form)
+}
+
 }  // namespace
 
 extern "C" {
@@ -490,7 +558,7 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(SKYJO_E_INVALID, "device_id out of range");
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, cfg->device_id));
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("SKYJO_ALLOW_ANY_GPU"))
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !sk_diag_env("SKYJO_ALLOW_ANY_GPU"))
     return fail(SKYJO_E_NOGPU, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950");
   DevGuard guard_(cfg->device_id);  // (the caller's current device is restored on return)
 
@@ -517,7 +585,7 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   const bool fixed_n = cfg->num_players >= 2 && cfg->num_players <= 4;
   h->lds_step = fixed_n ? h->lds_tile + (size_t)SK_TILE * (P.L.indirect ? 64 : P.L.rec_bytes + 16) : h->lds_bytes;
   h->lds_rollout = fixed_n ? h->lds_step + (size_t)cfg->num_players * 1024 : h->lds_bytes;
-  if (const char *e = getenv("SKYJO_LDS_PAD"))  // diagnostic: caps the wavefronts per CU
+  if (const char *e = sk_diag_env("SKYJO_LDS_PAD"))  // diagnostic: caps the wavefronts per CU
     h->lds_bytes += (size_t)atoi(e), h->lds_rollout += (size_t)atoi(e), h->lds_step += (size_t)atoi(e);
   const size_t rec16 = (size_t)P.tiles * P.L.chunks * SK_TILE;
   if ((uint64_t)SK_BANK * rec16 * 16 >= (1ull << 32)) {  // (LDS-DMA addresses the bank with 32-bit offsets)
@@ -595,12 +663,12 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
       uint8_t *d = (uint8_t *)dp;
       h->hm_actions = (int32_t *)h->hm_block, h->hm_mask = h->hm_block + a, h->hm_records = h->hm_block + a + m, h->hm_raw = h->hm_block + a + m + r;
       h->hm_actions_d = (int32_t *)d, h->hm_mask_d = d + a, h->hm_records_d = d + a + m, h->hm_raw_d = d + a + m + r;
-      h->fast_host = !getenv("SKYJO_NO_FAST_HOST");
-      h->host_spin = !getenv("SKYJO_NO_SPIN");
+      h->fast_host = !sk_diag_env("SKYJO_NO_FAST_HOST");
+      h->host_spin = !sk_diag_env("SKYJO_NO_SPIN");
       // Whole games come back with the records only for a few tiles (the single-game views: get_state / rewards after a step
       // without device traffic).  At raw_stride ~ 400 B per game the export is per-lane 16-byte stores at that stride over
       // PCIe - for a mid-size batch whose caller may never ask for a state that is dead weight.
-      h->raw_export = h->fast_host && P.tiles <= 4 && !getenv("SKYJO_NO_RAW_EXPORT");
+      h->raw_export = h->fast_host && P.tiles <= 4 && !sk_diag_env("SKYJO_NO_RAW_EXPORT");
     }
   }
   // The dealing kernel runs beside the step kernel (own stream) when the batch leaves SIMDs free: up to 768 tiles of
@@ -608,60 +676,13 @@ int skyjo_vec_create(const skyjo_vec_config *cfg, skyjo_vec **out) {
   // 49 152: 23.1 / 22.6, 57 344: 25.2 / 26.1, 65 536: 20.3 / 29.0 - on a full chip the two kernels compete for the same
   // vector ALUs), in line above that.  SKYJO_OPT_OVERLAP / SKYJO_OVERLAP override.
   h->overlap = P.tiles <= 768;
-  if (const char *e = getenv("SKYJO_OVERLAP")) h->overlap = atoi(e) != 0;
-  {
-    // k_cycle: S step + S dealing wavefronts per workgroup, S = what spreads the batch over the 256 CUs (1 .. 4); their LDS
-    // regions and the claim words must fit one CU's 160 KB
-    const int ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    int S = (P.tiles + ncu - 1) / ncu;
-    S = S < 1 ? 1 : (S > SK_CYCLE_MAX_S ? SK_CYCLE_MAX_S : S);
-    if (const char *e = getenv("SKYJO_CYCLE_S")) S = atoi(e) >= 1 && atoi(e) <= SK_CYCLE_MAX_S ? atoi(e) : S;
-    const size_t deal_region = (size_t)SK_TILE * (SK_DECK_STRIDE + SK_STG_STRIDE);
-    size_t per_s = h->lds_rollout + deal_region;
-    const int natural_s = S;
-    h->lds_cycle_step = h->lds_rollout, h->cycle_no_defer = false;
-    if ((size_t)S * per_s + 32 > 160 * 1024 && (size_t)S * (h->lds_step + deal_region) + 32 <= 160 * 1024 && cfg->num_players <= 3 &&
-        !getenv("SKYJO_CYCLE_DEFER_ONLY")) {
-      // the direct observation of three players on a full chip: the CU's share of tiles fits without the card chunks of the deferred
-      // scoring (the games are then scored in the iteration they end: a slower step, but one round of workgroups - 31.0 against 23.5
-      // x 10^9 in line; four players, where scoring on the spot costs more: 22.5 against 30.1 - they stay in line)
-      per_s = h->lds_step + deal_region;
-      h->lds_cycle_step = h->lds_step, h->cycle_no_defer = true;
-    }
-    while (S > 1 && (size_t)S * per_s + 32 > 160 * 1024) S--;  // (fewer wavefronts per workgroup, more workgroups)
-    const size_t need = (size_t)S * per_s + 32;
-    const bool fits = fixed_n && need <= 160 * 1024 && !getenv("SKYJO_LDS_PAD");
-    h->lds_cycle = need, h->cycle_s = S;
-    h->merged_capable = fits;
-    if (fits) {
-      const void *fn = P.L.indirect ? (cfg->num_players == 2 ? (const void *)k_cycle<true, 2, false> : cfg->num_players == 3 ? (const void *)k_cycle<true, 3, false> : (const void *)k_cycle<true, 4, false>)
-                                    : (cfg->num_players == 2 ? (const void *)k_cycle<false, 2, false> : cfg->num_players == 3 ? (const void *)k_cycle<false, 3, false> : (const void *)k_cycle<false, 4, false>);
-      const void *fnp = P.L.indirect ? (cfg->num_players == 2 ? (const void *)k_cycle<true, 2, true> : cfg->num_players == 3 ? (const void *)k_cycle<true, 3, true> : (const void *)k_cycle<true, 4, true>)
-                                     : (cfg->num_players == 2 ? (const void *)k_cycle<false, 2, true> : cfg->num_players == 3 ? (const void *)k_cycle<false, 3, true> : (const void *)k_cycle<false, 4, true>);
-      // (the attribute belongs to the function, not to the handle: always the whole CU, so that engines of different batch sizes -
-      // different S - can live side by side in one process)
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-          (fnp && hipFuncSetAttribute(fnp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)) {
-        (void)hipGetLastError();
-        h->merged_capable = false;
-      }
-    }
-    // Default: the one-kernel form wherever it fits (measured at 4 096 .. 65 536 games and two to four players: + 9 .. 32 % over the
-    // two-stream form, + 18 .. 57 % over dealing in line, EXPERIMENTS.md round 4); SKYJO_MERGED=0 falls back to the older forms.
-    // (Batches beyond four tiles per CU run in two or more rounds of workgroups - a workgroup's LDS fills its CU: 98 304 x 3 29.1
-    // against 23.8 in line, 131 072 x 3 34.0 against 21.0; counter-based deals 37.5 / 49.4 against 39.6 / 32.5: the one-kernel
-    // form still wins everywhere but at one and a half rounds of counter-based deals.  Not so where the LDS - not the batch - makes
-    // the workgroups smaller than a CU's share of the tiles, i.e. a full chip of four-player games or of the direct observation: S = 3,
-    // 342 workgroups in one and a third rounds, 25.5 against 30.0 and 17.5 against 23.6 in line.)
-    h->prefer_merged = S == natural_s;
-    if (const char *e = getenv("SKYJO_MERGED")) h->prefer_merged = atoi(e) != 0;
-    h->merged = h->merged_capable && h->prefer_merged && !getenv("SKYJO_OVERLAP");
-    if (h->merged) h->overlap = false;  // (no second stream in this form)
-  }
-  if (const char *e = getenv("SKYJO_FUSED_SCAN")) h->fused_scan = atoi(e) != 0;
-  if (const char *e = getenv("SKYJO_PIPELINED")) h->piped = atoi(e) != 0;
+  if (const char *e = sk_diag_env("SKYJO_OVERLAP")) h->overlap = atoi(e) != 0;
+  h->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  configure_cycle(h, 0);
+  if (const char *e = sk_diag_env("SKYJO_FUSED_SCAN")) h->fused_scan = atoi(e) != 0;
+  if (const char *e = sk_diag_env("SKYJO_PIPELINED")) h->piped = atoi(e) != 0;
   h->deal_every_iters = h->interval_default = deal_interval_default(cfg->num_players, h->overlap, h->piped, h->merged ? h->cycle_s : 0);
-  if (const char *e = getenv("SKYJO_DEAL_INTERVAL")) {
+  if (const char *e = sk_diag_env("SKYJO_DEAL_INTERVAL")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 1024) h->deal_every_iters = v, h->auto_interval = false;
   }
@@ -953,9 +974,10 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
     int cycles = 1;
     // (only where the kernel's cycle ends have a run to hand over: an engine that never deals ahead - SKYJO_OPT_NO_BANK - plans nothing,
     // and a cycle end inside its launch would publish and plan with a stale id: ADVICE r4)
-    if (h->merged && piped && run_due && h->pending_iters == 0 && !getenv("SKYJO_NO_MULTI_CYCLE")) {
+    if (h->merged && piped && run_due && h->pending_iters == 0) {
+      const int cap = h->max_cycles > 0 ? h->max_cycles : kMaxCyclesPerLaunch;
       cycles = (iters - done) / h->deal_every_iters;
-      cycles = cycles < 1 ? 1 : (cycles > kMaxCyclesPerLaunch ? kMaxCyclesPerLaunch : cycles);
+      cycles = cycles < 1 ? 1 : (cycles > cap ? cap : cycles);
       n = cycles * h->deal_every_iters;
     }
     if (run_due && piped) {
@@ -1466,6 +1488,10 @@ int skyjo_vec_get_option(const skyjo_vec *h, int option, int64_t *value_out) {
     case SKYJO_OPT_OVERLAP: *value_out = h->merged ? 3 : h->overlap ? 2 : 0; return SKYJO_OK;
     case SKYJO_OPT_NO_BANK: *value_out = h->no_bank ? 1 : 0; return SKYJO_OK;
     case SKYJO_OPT_RECORD_LAYOUT: *value_out = h->rec_planar ? SKYJO_REC_TILE_PLANAR : SKYJO_REC_ROW_MAJOR; return SKYJO_OK;
+    case SKYJO_OPT_INLINE_WORK_LIST: *value_out = h->fused_scan ? 0 : 1; return SKYJO_OK;
+    case SKYJO_OPT_UNPIPELINED: *value_out = h->piped ? 0 : 1; return SKYJO_OK;
+    case SKYJO_OPT_CYCLE_S: *value_out = h->cycle_s; return SKYJO_OK;
+    case SKYJO_OPT_MAX_CYCLES_PER_LAUNCH: *value_out = h->max_cycles > 0 ? h->max_cycles : kMaxCyclesPerLaunch; return SKYJO_OK;
     default: return fail(SKYJO_E_INVALID, "unknown option");
   }
 }
@@ -1501,6 +1527,32 @@ int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
       if (value == SKYJO_REC_TILE_PLANAR && !h->merged_capable)
         return fail(SKYJO_E_INVALID, "the tile-planar record layout exists for the one-kernel form of the fused rollout (two to four players)");
       h->rec_planar = value == SKYJO_REC_TILE_PLANAR;
+      return SKYJO_OK;
+    case SKYJO_OPT_INLINE_WORK_LIST:
+      h->fused_scan = value == 0;
+      return SKYJO_OK;
+    case SKYJO_OPT_UNPIPELINED: {
+      int rc = publish_deals(h, nullptr);  // drain the pipeline before changing its shape
+      if (rc) return rc;
+      HIPCHK(hipDeviceSynchronize());
+      h->piped = value == 0;
+      h->interval_default = deal_interval_default(h->P.L.N, h->overlap, h->piped, h->merged ? h->cycle_s : 0);
+      if (h->auto_interval) h->deal_every_iters = h->interval_default;
+      return SKYJO_OK;
+    }
+    case SKYJO_OPT_CYCLE_S: {
+      if (h->seeded) return fail(SKYJO_E_STATE, "SKYJO_OPT_CYCLE_S must be set before skyjo_vec_seed");
+      if (value < 0 || value > SK_CYCLE_MAX_S) return fail(SKYJO_E_INVALID, "SKYJO_OPT_CYCLE_S takes 0 (the batch's share) .. 4");
+      const bool was = h->merged;
+      configure_cycle(h, (int)value);
+      if (was && !h->merged_capable) return fail(SKYJO_E_INVALID, "that many step regions do not fit a compute unit's LDS");
+      h->interval_default = deal_interval_default(h->P.L.N, h->overlap, h->piped, h->merged ? h->cycle_s : 0);
+      if (h->auto_interval) h->deal_every_iters = h->interval_default;
+      return SKYJO_OK;
+    }
+    case SKYJO_OPT_MAX_CYCLES_PER_LAUNCH:
+      if (value < 1 || value > kMaxCyclesPerLaunch) return fail(SKYJO_E_INVALID, "SKYJO_OPT_MAX_CYCLES_PER_LAUNCH takes 1 .. 16");
+      h->max_cycles = (int)value;
       return SKYJO_OK;
     case SKYJO_OPT_DEBUG_SPIN_LOG2:
       if (value < 1 || value > 30) return fail(SKYJO_E_INVALID, "spin limit must be 2^1 .. 2^30");

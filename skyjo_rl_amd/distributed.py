@@ -65,13 +65,37 @@ def gather_stats(counters, num_players, device=None):
 
     rec = torch.tensor(stats_record(counters, num_players), dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized():
-        if dist.get_backend() == "gloo":  # (gloo gathers host tensors only; "nccl" = RCCL takes the device tensor as it is)
-            rec = rec.cpu()
-        else:
-            assert rec.is_cuda, "the RCCL all-gather takes the record where it lives: pass device=torch.device('cuda', i)"
-        out = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
+        world = dist.get_world_size()
+        on = _backend_devices(dist.get_backend())
+        kind = "cuda" if rec.is_cuda else "cpu"
+        if kind not in on:
+            # the group has no backend for where the record lives: take it to where the group works, or - one rank, nothing to
+            # exchange - leave it where it is (a single-rank "nccl" group with a host record used to assert)
+            if world == 1 and kind == "cpu":
+                allr = rec.numpy()[None]
+                return allr, combine_stats(allr, num_players)
+            if "cpu" in on:
+                rec = rec.cpu()
+            elif torch.cuda.is_available():
+                rec = rec.to(torch.device("cuda", torch.cuda.current_device()))
+            else:
+                raise ValueError(f"gather_stats: the process group's backend ({dist.get_backend()}) needs a device tensor and no GPU is visible")
+        out = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(out, rec)
         allr = torch.stack(out).cpu().numpy()
     else:
         allr = rec.cpu().numpy()[None]
     return allr, combine_stats(allr, num_players)
+
+
+def _backend_devices(backend):
+    """Device types ("cpu", "cuda") the default group's backend string serves: "nccl" (= RCCL) -> cuda, "gloo" -> cpu (this path
+    gathers host tensors through it), a mixed group "cpu:gloo,cuda:nccl" -> both, anything else (mpi, ucc) -> both."""
+    b = str(backend).lower()
+    if ":" in b:
+        return {part.split(":", 1)[0] for part in b.split(",")}
+    if b == "nccl":
+        return {"cuda"}
+    if b == "gloo":
+        return {"cpu"}
+    return {"cpu", "cuda"}

@@ -383,6 +383,10 @@ class SkyjoVecEnv:
         wavefronts share every CU; two to four players)."""
         _lib.check(self._L.skyjo_vec_set_option(self._h, 2, int(on)))
 
+    def set_option(self, option, value):
+        """skyjo_vec_set_option with one of ``_lib.OPT_*`` (include/skyjo_vec.h)."""
+        _lib.check(self._L.skyjo_vec_set_option(self._h, int(option), int(value)))
+
     def dealing_form(self):
         """'in line', 'two streams' or 'one kernel' (include/skyjo_vec.h: SKYJO_OPT_OVERLAP)."""
         v = C.c_int64()

@@ -61,7 +61,7 @@ CASES = [
     ("N4_S3_four_cycles", 49152, 4, True, 0, 0, 2, -4, 0),
     ("partial_wg_S3_multi_cycle", 40010, 2, True, 0, 0, 3, -4, 0),     # 626 tiles = 208 workgroups of 3 + one of 2; last tile 10 games
     ("partial_wg_S2_multi_cycle", 16400, 3, True, 0, 0, 3, -4, 0),     # 257 tiles = 128 workgroups of 2 + one of 1; last tile 16 games
-    ("surplus_wavefronts_S4_7_tiles", 440, 3, True, 0, 0, 4, -4, 0),   # SKYJO_CYCLE_S=4: one workgroup of 4 tiles + one of 3
+    ("surplus_wavefronts_S4_7_tiles", 440, 3, True, 0, 0, 4, -4, 0),   # SKYJO_OPT_CYCLE_S = 4: one workgroup of 4 tiles + one of 3
     ("direct_obs_eight_cycles", 65536, 3, False, 0, 0, 1, -8, 0),      # (bench's other_configs.direct_obs_65536x3 launch)
     ("philox_eight_cycles", 65536, 3, True, 1, 0, 1, -8, 0),           # (other_configs.philox_65536x3)
     # the launches bench.py times since round 5: records in the tile-planar layout (SKYJO_OPT_RECORD_LAYOUT), sixteen cycles per launch
@@ -84,15 +84,16 @@ SLICE = 64  # iterations the oracle records at a time
 
 
 @pytest.mark.parametrize("name,B,N,ind,rng_mode,gid0,launches,K,interval", CASES, ids=[c[0] for c in CASES])
-def test_every_game_of_the_batch_against_the_oracle(name, B, N, ind, rng_mode, gid0, launches, K, interval, monkeypatch):
+def test_every_game_of_the_batch_against_the_oracle(name, B, N, ind, rng_mode, gid0, launches, K, interval):
     import torch
     from oracle import skyjo_oracle as so
     from skyjo_rl_amd import SkyjoVecEnv
 
-    if name == "surplus_wavefronts_S4_7_tiles":
-        monkeypatch.setenv("SKYJO_CYCLE_S", "4")  # (read when the engine is created)
     cfg = _cfg(N, ind, rng_mode)
     eng = SkyjoVecEnv(B, game_id0=gid0, **cfg)
+    if name == "surplus_wavefronts_S4_7_tiles":
+        from skyjo_rl_amd import _lib
+        eng.set_option(_lib.OPT_CYCLE_S, 4)  # (before the engine is seeded)
     ora = so.OracleVec(num_envs=B, game_id0=gid0, **cfg)
     if interval > 0:
         eng.set_deal_interval(interval)

@@ -208,7 +208,7 @@ def test_rollout_vs_oracle(N, ind, rng_mode, B):
 
 @pytest.mark.parametrize("interval,overlap", [(1, False), (16, False), (1000, False), (8, True), (64, True), (8, 2), (64, 2), (8, 3), (40, 3)])
 @pytest.mark.parametrize("N,rng_mode", [(2, 0), (3, 0), (4, 0), (12, 0), (1, 1), (1, 0), (8, 1)])
-def test_deal_cadence_does_not_change_results(N, rng_mode, interval, overlap):
+def test_deal_cadence_does_not_change_results(N, rng_mode, interval, overlap, options=None):
     """However rarely the dealing kernel runs (bank of pre-dealt episodes full, partly filled or empty - then the
     lane deals in place), whether it runs in line (overlap 0 / False), on its own stream beside the step kernels (2) or inside the
     step kernel's own workgroups (3: k_cycle; True = whichever of the two the engine prefers) - then the rare
@@ -224,6 +224,8 @@ def test_deal_cadence_does_not_change_results(N, rng_mode, interval, overlap):
     eng = _engine(B, **cfg)
     eng.set_deal_interval(interval)
     eng.set_overlap(overlap)
+    for opt, val in (options or {}).items():
+        eng.set_option(opt, val)
     assert eng.dealing_form() == {0: "in line", 2: "two streams", 3: "one kernel"}.get(int(overlap), eng.dealing_form())
     ora = _oracle_vec(num_envs=B, **cfg)
     eng.seed(None, 31)
@@ -248,19 +250,19 @@ def test_deal_cadence_does_not_change_results(N, rng_mode, interval, overlap):
 
 
 @pytest.mark.parametrize("N,rng_mode,interval", [(3, 0, 16), (2, 0, 1000), (12, 0, 8), (8, 1, 16)])
-def test_inline_dealing_with_work_list_form(N, rng_mode, interval, monkeypatch):
-    """In line the dealing kernel scans the banks itself (lane = game); SKYJO_FUSED_SCAN=0 selects the k_scan + work list
+def test_inline_dealing_with_work_list_form(N, rng_mode, interval):
+    """In line the dealing kernel scans the banks itself (lane = game); SKYJO_OPT_INLINE_WORK_LIST selects the k_scan + work list
     form the dealing run beside the step kernel uses, here in line: same results."""
-    monkeypatch.setenv("SKYJO_FUSED_SCAN", "0")
-    test_deal_cadence_does_not_change_results(N, rng_mode, interval, False)
+    from skyjo_rl_amd import _lib
+    test_deal_cadence_does_not_change_results(N, rng_mode, interval, False, options={_lib.OPT_INLINE_WORK_LIST: 1})
 
 
 @pytest.mark.parametrize("N,rng_mode,interval", [(3, 0, 8), (2, 0, 64), (12, 0, 8), (8, 1, 64)])
-def test_dealing_beside_the_step_kernel_with_scan_and_publish_kernels(N, rng_mode, interval, monkeypatch):
+def test_dealing_beside_the_step_kernel_with_scan_and_publish_kernels(N, rng_mode, interval):
     """Beside the step kernel the dealing runs are pipelined by default (the step kernel plans and publishes them itself);
-    SKYJO_PIPELINED=0 selects the k_scan / k_publish form whose caller's stream waits for every run: same results."""
-    monkeypatch.setenv("SKYJO_PIPELINED", "0")
-    test_deal_cadence_does_not_change_results(N, rng_mode, interval, True)
+    SKYJO_OPT_UNPIPELINED selects the k_scan / k_publish form whose caller's stream waits for every run: same results."""
+    from skyjo_rl_amd import _lib
+    test_deal_cadence_does_not_change_results(N, rng_mode, interval, True, options={_lib.OPT_UNPIPELINED: 1})
 
 
 @pytest.mark.parametrize("seed,N,B", [(1, 3, 1024), (2, 2, 700), (3, 4, 2048)])

@@ -18,8 +18,22 @@ def short(name):
     return name.split("(")[0].replace("void ", "").strip()
 
 
-def rank_stats(rank_dir):
-    """(kernel, calls, avg us) of the dominant kernel (k_cycle or k_step) from the rank's *kernel_stats.csv."""
+def rank_stats(rank_dir, timed):
+    """(kernel, dispatches in the trace, average us over the LAST `timed` of them) of the dominant kernel (k_cycle or k_step) from the
+    rank's *kernel_trace.csv - the settle and warm-up launches (other dealing intervals, other iteration counts) stay out of it, as in
+    bench.py's own roofline figure; the *kernel_stats.csv average over all calls is the fall-back."""
+    hits = sorted(glob.glob(os.path.join(rank_dir, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+    if hits:
+        per = {}
+        for r in csv.DictReader(open(hits[-1])):
+            k = short(r["Kernel_Name"])
+            if k.startswith("k_cycle") or k.startswith("k_step"):
+                per.setdefault(k, []).append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+        if per:
+            k = max(per, key=lambda n: sum(d for _, d in per[n]))
+            d = [x[1] for x in sorted(per[k])]
+            last = d[-max(1, int(timed)):]
+            return k, len(d), sum(last) / len(last)
     hits = sorted(glob.glob(os.path.join(rank_dir, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if not hits:
         return None
@@ -39,7 +53,7 @@ def point(n):
     alg = line["roofline"]["algorithmic_bytes_per_launch"]
     ranks = []
     for r in range(n):
-        st = rank_stats(os.path.join(d, "rank%d" % r))
+        st = rank_stats(os.path.join(d, "rank%d" % r), line["roofline"].get("launches_timed", 32))
         if st is None:
             ranks.append({"rank": r, "error": "no kernel_stats.csv"})
             continue
@@ -48,14 +62,16 @@ def point(n):
         ranks.append({"rank": r, "kernel": k, "calls": calls, "avg_us": avg_us, "achieved_GBs": gbs, "frac_of_peak": gbs / PEAK_GBS})
     out = {"n_gpus": n, "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "scaling": line["scaling"],
            "collective": line["config"]["collective"], "algorithmic_bytes_per_launch": alg, "peak_GBs": PEAK_GBS, "ranks": ranks,
-           "note": "per rank: rocprofv3 --kernel-trace --stats of that rank's own process (tools/scale_run.sh); value: bench.py's line (rank 0)"}
+           "bench_achieved_GBs": line["roofline"].get("achieved"), "launches_timed": line["roofline"].get("launches_timed", 32),
+           "note": "per rank: rocprofv3 --kernel-trace --stats of that rank's own process (tools/scale_run.sh), average over the last "
+                   "`launches_timed` dispatches of the dominant kernel; value / bench_achieved_GBs: bench.py's own line (rank 0, HIP events)"}
     json.dump(out, open(os.path.join(d, "scale_point.json"), "w"), indent=1)
     return out
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--table":
-        tag = sys.argv[2] if len(sys.argv) > 2 else "r5"
+        tag = sys.argv[2] if len(sys.argv) > 2 else "r6"
         pts = []
         for d in sorted(glob.glob(os.path.join(BASE, "N*")), key=lambda p: int(os.path.basename(p)[1:])):
             f = os.path.join(d, "scale_point.json")
