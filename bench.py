@@ -64,7 +64,7 @@ SETTLE = int(os.environ.get("SKYJO_BENCH_SETTLE", "100"))  # launches between se
 # build container (8-core Xeon 2.1 GHz); the reference cannot travel to the GPU box, so these are constants
 REFERENCE_STEPS_PER_S_1_CORE = 8.3e3
 REFERENCE_STEPS_PER_S_8_CORES = 52.8e3
-TRAFFIC_PROFILE = os.path.join("profiles", "r5_hbm_traffic.json")  # rocprofv3 PMC passes of this very launch shape (tools/refresh_profiles.sh)
+TRAFFIC_PROFILE = os.path.join("profiles", "r6_hbm_traffic.json")  # rocprofv3 PMC passes of this very launch shape (tools/refresh_profiles.sh)
 # (the environment's translation unit: skyjo_device.h and its parts; the policy net's unit - skyjo_policy.* - has nothing to do with k_cycle's traffic)
 KERNEL_SOURCES = ("skyjo_rl_amd/csrc/skyjo_device.h", "skyjo_rl_amd/csrc/skyjo_rng.h", "skyjo_rl_amd/csrc/skyjo_transition.h",
                   "skyjo_rl_amd/csrc/skyjo_record.h", "skyjo_rl_amd/csrc/skyjo_step.h", "skyjo_rl_amd/csrc/skyjo_deal.h",
@@ -351,7 +351,7 @@ def main():
     ap.add_argument("--actions-array", action="store_true", help="also write the int32 action array (the action is byte D of every record anyway)")
     ap.add_argument("--record-layout", choices=["auto", "row-major", "tile-planar"], default=os.environ.get("SKYJO_BENCH_RECORD_LAYOUT", "auto"),
                     help="how the fused rollout lays out its records (include/skyjo_vec.h: SKYJO_OPT_RECORD_LAYOUT); auto = tile-planar "
-                         "wherever the kernel exists (one-kernel form, indirect observation), row-major otherwise")
+                         "wherever the kernel exists (the one-kernel form, either observation), row-major otherwise")
     ap.add_argument("--direct-obs", action="store_true", help="observe_other_player_indirect=False: D = 19 + 12 N (not the headline)")
     args = ap.parse_args()
 
@@ -429,7 +429,11 @@ def main():
     run(args.warmup)
     blocks = []
     for b in range(max(args.blocks, 1)):
-        barrier()
+        # Between two blocks the host reads counters and gathers statistics - 50 .. 200 us without a launch, after which the next
+        # ~ 8 launches run up to 10 % slower (the kernel trace of profiles/r6_kernel_trace_digest.json: the clock comes back over
+        # ~ 10 ms).  A block therefore starts like the first one does, behind untimed launches: W of them again, at most 8.
+        if b > 0:
+            run(min(args.warmup, 8))
         eng.reset_counters()
         barrier()
         t0 = time.perf_counter()

@@ -141,7 +141,7 @@ struct skyjo_vec {
   uint32_t cycle_seq = 0;   // k_cycle launches so far: launch L counts empty banks into bank_empty[L & 1] and reports the other word
   int ncu = 256;            // compute units of the device (k_cycle's workgroup sizing)
   int max_cycles = 0;       // SKYJO_OPT_MAX_CYCLES_PER_LAUNCH (0: the ABI's maximum, kMaxCyclesPerLaunch)
-  bool rec_planar = false;  // SKYJO_OPT_RECORD_LAYOUT: skyjo_vec_rollout writes its records tile-planar (one-kernel form, indirect observation)
+  bool rec_planar = false;  // SKYJO_OPT_RECORD_LAYOUT: skyjo_vec_rollout writes its records tile-planar (one-kernel form, either observation)
   bool no_bank = false;  // SKYJO_OPT_NO_BANK: no pre-dealt episodes, every deal is made in place from the stream's position
   // lazily allocated scratch for the *_host conveniences
   int32_t *d_actions = nullptr;

@@ -261,6 +261,24 @@ __device__ __forceinline__ void deck_batch(Rng &r, const int s, uint32_t *lds_ra
   constexpr uint32_t R = SK_NCARDS - 12 * NP;
   constexpr int BS = SK_DECK_BS;
   uint32_t pI[BS], pJ[BS];
+#ifdef SK_EXP_DECK_FAST
+  // round-6 experiment: while no lane of the wavefront can complete a shuffle inside this batch - every n is
+  // either 0 (done) or beyond BS + 1 - the five instructions per draw that handle a completion are left out
+  if (__all(w.n == 0u || w.n > (uint32_t)(BS + 1))) {
+#pragma unroll
+    for (int k = 0; k < BS; k++) {
+      const uint32_t v = r.R[s + k] & w.mask;
+      const bool acc = PRO ? (v < w.n && s + k >= r.pos) : (v < w.n);
+      pI[k] = w.pcur;
+      pJ[k] = acc ? w.pb + v : w.pcur;
+      const uint32_t d = acc ? 0xffffffffu : 0u;
+      w.n += d;
+      w.pcur += d;
+      w.mask = 0xffffffffu >> __builtin_clz(w.n - 1u);
+    }
+  } else
+#endif
+  {
 #pragma unroll
   for (int k = 0; k < BS; k++) {
     const uint32_t v = r.R[s + k] & w.mask;
@@ -277,6 +295,7 @@ __device__ __forceinline__ void deck_batch(Rng &r, const int s, uint32_t *lds_ra
     w.mask = 0xffffffffu >> __builtin_clz(w.n - 1u);  // (n - 1 is never 0)
   }
   w.nxt_n = w.pb == dk ? R : 0u;  // (a batch never holds two completions: the rest takes > 100 draws)
+  }
   uint32_t cI[BS], cJ[BS];
 #pragma unroll
   for (int k = 0; k < BS; k++) cI[k] = DK_AT(pI[k]), cJ[k] = DK_AT(pJ[k]);

@@ -1,6 +1,6 @@
 """DESIGN.md section 6 quotes its figures from the committed profiles/ files (it once quoted a best box instead).
 This test re-reads both: the kernel's average launch time, `value`, the roofline fraction and the traffic figure in DESIGN.md must be
-within 2 % of profiles/r5_kernel_stats.csv / r5_bench.json / r5_hbm_traffic.json, and the section must be what
+within 2 % of profiles/r6_kernel_stats.csv / r6_bench.json / r6_hbm_traffic.json, and the section must be what
 tools/design_section6.py generates from them."""
 import csv
 import json
@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = "r5"
+R = "r6"
 
 
 def _num(text):
@@ -46,7 +46,10 @@ def test_quoted_kernel_time_value_fraction_and_traffic_match_the_committed_profi
     m = re.search(r"`roofline.traffic` \| \*\*(\d+\.\d\d) GB\*\*", sec)
     assert m and abs(float(m.group(1)) * 1e9 - traffic["k_step_bytes_per_launch"]) <= 0.02 * traffic["k_step_bytes_per_launch"]
     # the line's own traffic field is the digest's (bench.py only reports it for the kernel sources it was measured on)
-    assert bench["roofline"]["traffic"] in (None, traffic["k_step_bytes_per_launch"])
+    # (or the digest of the refresh before: the line of a refresh run carries the digest committed when it ran, and two refreshes of the
+    # same kernel differ in the fifth digit)
+    tr = bench["roofline"]["traffic"]
+    assert tr is None or abs(tr - traffic["k_step_bytes_per_launch"]) <= 1e-3 * traffic["k_step_bytes_per_launch"]
 
 
 def test_section_is_what_the_generator_writes():
@@ -54,4 +57,4 @@ def test_section_is_what_the_generator_writes():
                           "import sys; sys.path.insert(0, %r); sys.argv = ['x', %r]; import design_section6 as d; print(d.text())" % (os.path.join(ROOT, "tools"), R)],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.strip() in _section6(), "DESIGN.md section 6 is stale: run `python tools/design_section6.py r5`"
+    assert out.stdout.strip() in _section6(), "DESIGN.md section 6 is stale: run `python tools/design_section6.py r6`"

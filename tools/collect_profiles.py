@@ -3,7 +3,7 @@
 import collections, csv, glob, json, os, shutil, sys
 sys.path.insert(0, os.getcwd())
 src, dst = "gpurun_out/final", "profiles"
-R = sys.argv[1] if len(sys.argv) > 1 else "r5"
+R = sys.argv[1] if len(sys.argv) > 1 else "r6"
 def find(pat):  # newest match: gpurun merges every refresh into the same local directory
     r = sorted(glob.glob(os.path.join(src, pat), recursive=True), key=os.path.getmtime)
     return r[-1] if r else None
@@ -27,6 +27,29 @@ for k, v in per.items():
     d = [x[1] for x in v]
     digest.append({"kernel": k, "calls": len(d), "avg_us": sum(d) / len(d), "last32_avg_us": sum(d[-32:]) / len(d[-32:]),
                    "min_us": min(d), "max_us": max(d)})
+# where the long launches are: the first launches after seeding, and the launches behind a pause of the launch stream
+for k, v in per.items():
+    if not k.startswith("k_cycle"):
+        continue
+    v.sort()
+    d = [x[1] for x in v]
+    full = sorted(x for x in d if x > 0.5 * max(d))
+    med = full[len(full) // 2]
+    slow = [(i, x) for i, x in enumerate(d) if x > 1.05 * med]
+    allk = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows)
+    ends = {}
+    for i in range(1, len(allk)):
+        ends[allk[i][0]] = (allk[i][0] - allk[i - 1][1]) / 1e3   # idle time in front of every dispatch, us
+    pauses = [i for i, x in enumerate(v) if ends.get(x[0], 0.0) > 40.0]
+    digest.append({"kernel": k, "launch_time_tail": {
+        "median_us": med, "launches_over_105pct_of_median": len(slow), "of": len(d),
+        "in_the_first_16_after_seeding": sum(1 for i, _ in slow if i < 16), "max_us_in_the_first_16": max([x for i, x in slow if i < 16], default=None),
+        "within_12_launches_behind_a_pause_over_40us": sum(1 for i, _ in slow if i >= 16 and any(0 <= i - p0 <= 12 for p0 in pauses)),
+        "max_us_behind_a_pause": max([x for i, x in slow if i >= 16 and any(0 <= i - p0 <= 12 for p0 in pauses)], default=None),
+        "elsewhere": sum(1 for i, _ in slow if i >= 16 and not any(0 <= i - p0 <= 12 for p0 in pauses)),
+        "pauses_at_launch": pauses,
+        "note": "launch index counts this kernel's dispatches from the seeding on (100 set-up launches first); a pause = more than 40 us "
+                "without any kernel in front of the dispatch (the host reading counters / gathering statistics between two timed blocks)"}})
 digest.append({"note": "same run, bench.py's own HIP-event figure for the last 32 k_step launches",
                "avg_launch_ms": tb["roofline"]["avg_launch_ms"], "deal_kernel_avg_ms": tb["roofline"]["deal_kernel_avg_ms"]})
 json.dump(digest, open(os.path.join(dst, R + "_kernel_trace_digest.json"), "w"), indent=1)
@@ -41,6 +64,18 @@ for tag in ("fetch", "write", "sq", "sq2", "ea", "l2", "issue"):
         k = short(r["Kernel_Name"])
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
     pmc[tag] = {k: dict({"dispatches": len(n[k])}, **{c: v / len(n[k]) for c, v in agg[k].items()}) for k in agg}
+f = find("deckfast_pmc_sq/**/*counter_collection.csv")  # round 6, experiment 11: the -DSK_EXP_DECK_FAST build's counters beside the shipped kernel's
+if f:
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
+    pmc["deckfast_sq"] = {k: dict({"dispatches": len(n[k])}, **{c: v / len(n[k]) for c, v in agg[k].items()}) for k in agg}
+    try:
+        pmc["deckfast_sq"]["bench_value"] = json.loads(open(os.path.join(src, "deckfast_pmc_sq.json")).read().strip().splitlines()[-1])["value"]
+        pmc["sq"]["bench_value"] = json.loads(open(os.path.join(src, "pmc_sq.json")).read().strip().splitlines()[-1])["value"]
+    except Exception as e:
+        print("deckfast:", e)
 json.dump(pmc, open(os.path.join(dst, R + "_pmc_per_dispatch.json"), "w"), indent=1)
 merged = any(k.startswith("k_cycle") for k in pmc["fetch"])
 ks = [k for k in pmc["fetch"] if k.startswith("k_cycle" if merged else "k_step")][0]
@@ -105,6 +140,14 @@ attr = {"note": "per dispatch of the dominant kernel, bench.py's launch shape (t
         "philox_records": side_pmc("philox"), "mt19937_no_records": side_pmc("norec")}
 json.dump(attr, open(os.path.join(dst, R + "_hbm_traffic_attribution.json"), "w"), indent=1)
 # config 5
+c1 = os.path.join(src, "cfg1.json")
+if os.path.exists(c1):
+    try:
+        json.dump(json.loads(open(c1).read().strip().splitlines()[-1]), open(os.path.join(dst, R + "_cfg1.json"), "w"), indent=1)
+    except Exception as e:
+        print("cfg1:", e)
+import subprocess
+subprocess.run([sys.executable, os.path.join("tools", "r6_pmc_digest.py")], stdout=subprocess.DEVNULL)  # -> profiles/r6_cfg5_pmc.json, r6_pmc_philox.json
 c5 = os.path.join(src, "cfg5.json")
 if os.path.exists(c5):
     shutil.copy(c5, os.path.join(dst, R + "_cfg5_bench.json"))

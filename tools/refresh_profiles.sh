@@ -27,6 +27,16 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
   set -- $pass; tag=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/norec_pmc_$tag" -- python3 "$root/bench.py" --no-records --steps 30 --warmup 10 --blocks 1 --no-cpu-baseline --no-other-configs > "$out/norec_pmc_$tag.json" 2> "$out/norec_pmc_$tag.err"; echo "norec pmc $tag rc=$?"
 done
+# round 6, VERDICT r5 item 4: the same launch with the dealing walk's completion handling hoisted out of the per-draw path
+# (-DSK_EXP_DECK_FAST build, parity green, SLOWER: EXPERIMENTS.md round 6) - its instruction counters beside the shipped kernel's
+if [ -f "$root/build_exp/libskyjo_vec_deckfast.so" ]; then
+  SKYJO_LIB="$root/build_exp/libskyjo_vec_deckfast.so" rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d "$out/deckfast_pmc_sq" -- python3 "$root/bench.py" --steps 30 --warmup 10 --blocks 1 --no-cpu-baseline --no-other-configs > "$out/deckfast_pmc_sq.json" 2> "$out/deckfast_pmc_sq.err"; echo "deckfast pmc sq rc=$?"
+fi
+# round 6: counter passes on the policy net's kernels and the SQ passes of the counter-based-deals launch shape (tools/r6_pmc.sh -> gpurun_out/r6pmc/)
+cd "$root"
+bash tools/r6_pmc.sh cfg5 philox
+# config 1 (one game driven from Python through the reference's own loops)
+python3 tools/bench_cfg1.py > "$out/cfg1.json" 2> "$out/cfg1.err"; echo "cfg1 rc=$?"
 # config 5 (65 536 x 4 players, the action-mask model on the matrix cores picks every action): bench line + kernel stats
 cd "$root"
 python3 tools/bench_cfg5.py 65536 64 8 > "$out/cfg5.json" 2> "$out/cfg5.err"; echo "cfg5 rc=$?"
