@@ -117,6 +117,34 @@ def test_policy_and_value_net_in_one_launch_over_many_ragged_batches(precision):
     pol.close(), val.close(), env.close()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("obs_dim,out_dim,rec_bytes,n", [(17, 5, 48, 777), (1, 32, 32, 64), (31, 1, 112, 4100)])
+def test_net_on_caller_records_of_other_shapes(obs_dim, out_dim, rec_bytes, n, precision):
+    """skyjo_vec_mlp_forward takes any records of record_bytes >= 32 (a multiple of 16) whose first obs_dim <= 31 bytes are int8
+    features: the bytes from obs_dim on - here random - must not enter (the kernel clears them word-wise and puts the constant 1 that
+    carries layer 1's bias into byte 31)."""
+    import torch
+    from torch import nn
+
+    from skyjo_rl_amd.action_mask_model import FusedNet
+
+    torch.manual_seed(obs_dim)
+    seq = nn.Sequential(nn.Linear(obs_dim, 256), nn.Tanh(), nn.Linear(256, 256), nn.Tanh(), nn.Linear(256, out_dim)).cuda()
+    net = FusedNet(seq, precision=precision)
+    rec = torch.randint(0, 256, (n, rec_bytes), dtype=torch.uint8, device="cuda")
+    x = rec.view(torch.int8)[:, :obs_dim].to(torch.float32) * 0.25  # (smaller features: the net is not saturated)
+    rec8 = rec.clone()
+    rec8.view(torch.int8)[:, :obs_dim] = (x * 1.0).to(torch.int8)  # features in [-32, 31]
+    x = rec8.view(torch.int8)[:, :obs_dim].to(torch.float32)
+    got = net(rec8)
+    with torch.no_grad():
+        ref = seq(x)
+    tol = TOL[precision]
+    d = (got - ref).abs()
+    assert got.shape == (n, out_dim) and float(d.max()) <= 4 * tol["max"] and float(d.mean()) <= 4 * tol["mean"], (float(d.max()), float(d.mean()))
+    net.close()
+
+
 def test_fused_policy_loop_plays_legal_games():
     import torch
 
