@@ -271,6 +271,10 @@ def side_model_config(precision, B, N, T, rounds, device):
 
     torch.manual_seed(0)
     env = SkyjoVecEnv(B, num_players=N, device=device, **ENV_CFG)
+    layout = os.environ.get("SKYJO_BENCH_CFG5_LAYOUT", "row-major")  # ("tile-planar-all": the step kernel writes / the nets read planar blocks)
+    if layout != "row-major":
+        env.set_overlap(3)
+        env.set_record_layout(layout)
     env.seed(None, 3)
     model = ActionMaskModel(obs_dim=env.obs_dim).cuda()
     pol, val = FusedNet(model.policy, device=device, precision=precision), FusedNet(model.value, device=device, precision=precision)
@@ -297,7 +301,7 @@ def side_model_config(precision, B, N, T, rounds, device):
     flops = 2.0 * B * 2 * (32 * 256 + 256 * 256 + 256 * 32)  # policy + value net, the model's own (float32) multiply-adds
     out = {"workload": f"{B} x {N}-player games, action-mask model (policy + value net, 256-256 tanh, random weights) picks every action; "
                        f"skyjo_vec_model_rollout: 2 launches per lockstep iteration, rollout columns written",
-           "precision": precision, "value": c["steps"] / dt, "unit": "env-steps/s", "ms_per_iteration": 1e3 * dt / (rounds * T),
+           "precision": precision, "record_layout": layout, "value": c["steps"] / dt, "unit": "env-steps/s", "ms_per_iteration": 1e3 * dt / (rounds * T),
            "timed_iterations": rounds * T, "dominant_kernel": "k_net_split" if precision == "fp32" else "k_net_bf16",
            "dominant_kernel_ms": mlp_ms, "step_kernel_ms": prof["step_ms"] / max(prof["step_launches"], 1),
            "roofline_bound": "mfma", "roofline_achieved_tflops": flops / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else None,

@@ -274,7 +274,7 @@ int skyjo_vec_debug_trace(skyjo_vec *h, uint64_t *out_host);
  * stream's current position, exactly when the reference would (skyjo.py:52-74).  Slow for batches; it is what lets ONE
  * game share the process-global numpy stream with its caller (skyjo_vec_rng_set_state / _get_state below). */
 #define SKYJO_OPT_NO_BANK 5
-/* SKYJO_OPT_RECORD_LAYOUT - how skyjo_vec_rollout lays out records_out (every other call writes row-major records):
+/* SKYJO_OPT_RECORD_LAYOUT - how skyjo_vec_rollout lays out records_out (every other call writes row-major records unless ..._ALL below is chosen):
  *   SKYJO_REC_ROW_MAJOR    [iters][num_envs][record_bytes] - the default;
  *   SKYJO_REC_TILE_PLANAR  [iters][tiles][P][64][16], tiles = ceil(num_envs / 64), P = record_bytes / 16 (4 for the indirect
  *                          observation; 5 / 6 / 7 for the direct one with 2 / 3 / 4 players): the record of game 64 t + l is cut into
@@ -287,6 +287,11 @@ int skyjo_vec_debug_trace(skyjo_vec *h, uint64_t *out_host);
 #define SKYJO_OPT_RECORD_LAYOUT 6
 #define SKYJO_REC_ROW_MAJOR 0
 #define SKYJO_REC_TILE_PLANAR 1
+/* SKYJO_REC_TILE_PLANAR_ALL (round 6; indirect observation, two to four players): as SKYJO_REC_TILE_PLANAR, and every other device-style call
+ * that writes records - skyjo_vec_reset, _observe, _step, _step_collect, _model_rollout (its records buffer is then
+ * [T + 1][tiles][P][64][16]) - writes them tile-planar too, so that a rollout with the policy net never holds a row-major record
+ * (the net, the masked draw and the episode-end columns read the blocks in place: skyjo_vec_*_layout).  The *_host calls stay row-major. */
+#define SKYJO_REC_TILE_PLANAR_ALL 2
 /* The older forms of a dealing run, kept for the engines the one-kernel form does not cover and selectable so that the parity tests
  * can hold them against the oracle (results never depend on them):
  *   SKYJO_OPT_INLINE_WORK_LIST 1: an in-line run uses the k_scan + work-list form (default 0: the dealing kernel scans the banks itself);

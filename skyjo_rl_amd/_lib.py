@@ -73,7 +73,7 @@ class RolloutBuffers(C.Structure):
 
 
 # option ids / record layouts of include/skyjo_vec.h
-OPT_RECORD_LAYOUT, REC_ROW_MAJOR, REC_TILE_PLANAR = 6, 0, 1
+OPT_RECORD_LAYOUT, REC_ROW_MAJOR, REC_TILE_PLANAR, REC_TILE_PLANAR_ALL = 6, 0, 1, 2
 OPT_INLINE_WORK_LIST, OPT_UNPIPELINED, OPT_CYCLE_S, OPT_MAX_CYCLES_PER_LAUNCH = 7, 8, 9, 10
 
 # name -> (restype, argtypes); this table is also what tests/test_capi_symbols.py checks against the header

@@ -100,6 +100,8 @@ class FusedNet:
         (the rows beyond ``num_envs`` of a partial last tile are computed from whatever the block holds)."""
         rb = int(records.shape[-3] * 16) if planar else int(records.shape[-1])
         n = records.numel() // rb
+        if out is not None:  # (planar blocks are whole tiles: the caller's output says how many games there are)
+            n = min(n, out.numel() // self.out_dim)
         if out is None:
             out = torch.empty((n, self.out_dim), dtype=torch.float32, device=records.device)
         C = self._C

@@ -141,6 +141,7 @@ struct skyjo_vec {
   uint32_t cycle_seq = 0;   // k_cycle launches so far: launch L counts empty banks into bank_empty[L & 1] and reports the other word
   int ncu = 256;            // compute units of the device (k_cycle's workgroup sizing)
   int max_cycles = 0;       // SKYJO_OPT_MAX_CYCLES_PER_LAUNCH (0: the ABI's maximum, kMaxCyclesPerLaunch)
+  bool rec_planar_all = false;  // ... = SKYJO_REC_TILE_PLANAR_ALL: reset / observe / step / step_collect / model_rollout write their records tile-planar as well
   bool rec_planar = false;  // SKYJO_OPT_RECORD_LAYOUT: skyjo_vec_rollout writes its records tile-planar (one-kernel form, either observation)
   bool no_bank = false;  // SKYJO_OPT_NO_BANK: no pre-dealt episodes, every deal is made in place from the stream's position
   // lazily allocated scratch for the *_host conveniences
@@ -380,7 +381,7 @@ int start_deals_piped(skyjo_vec *h, hipStream_t s) {
 
 int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions, uint8_t *rec, int32_t *act_out,
                 int iters, uint64_t policy_seed, double *end_rew = nullptr, uint8_t *end_flag = nullptr, uint8_t *raw_out = nullptr,
-                int cycle_len = 0) {
+                int cycle_len = 0, bool planar_out = false) {
   h->raw_valid = false;  // (the host's copy of the games is stale from here on; step_host sets it again)
   dim3 grid(h->P.tiles), block(SK_TILE);
   const bool ind = h->P.L.indirect != 0;
@@ -444,7 +445,16 @@ int launch_step(skyjo_vec *h, hipStream_t s, bool policy, const int32_t *actions
     case 4: LAUNCH3(I, Pol, 4); break;                \
     default: LAUNCH3(I, Pol, 0); break;               \
   }
-  if (ind && policy) LAUNCH(true, true)
+  if (ind && !policy && planar_out) {  // (SKYJO_REC_TILE_PLANAR_ALL: two to four players, indirect observation - checked when the option is set)
+#define LAUNCHP(NP) hipExtLaunchKernelGGL((k_step<true, false, NP, true>), grid, block, (uint32_t)h->lds_step, s, e0, e1, 0, h->P, actions, rec, act_out, iters, \
+                                          policy_seed, h->iter, end_rew, end_flag, raw_out, h->raw_stride)
+    switch (h->P.L.N) {
+      case 2: LAUNCHP(2); break;
+      case 3: LAUNCHP(3); break;
+      default: LAUNCHP(4); break;
+    }
+#undef LAUNCHP
+  } else if (ind && policy) LAUNCH(true, true)
   else if (ind) LAUNCH(true, false)
   else if (policy) LAUNCH(false, true)
   else LAUNCH(false, false)
@@ -860,15 +870,15 @@ int skyjo_vec_snapshot_destroy(skyjo_vec_snapshot *sn) {
   return SKYJO_OK;
 }
 
-static int reset_impl(skyjo_vec *h, const uint8_t *mask, void *records_out, hipStream_t s, uint8_t *raw_out) {
+static int reset_impl(skyjo_vec *h, const uint8_t *mask, void *records_out, hipStream_t s, uint8_t *raw_out, int planar = 0) {
   int rc;
   h->raw_valid = false;
   if ((rc = publish_deals(h, s))) return rc;  // make every dealt episode available
   dim3 grid(h->P.tiles), block(SK_TILE);
   if (h->P.L.indirect)
-    hipLaunchKernelGGL((k_reset<true>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out, raw_out, h->raw_stride);
+    hipLaunchKernelGGL((k_reset<true>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out, raw_out, h->raw_stride, planar);
   else
-    hipLaunchKernelGGL((k_reset<false>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out, raw_out, h->raw_stride);
+    hipLaunchKernelGGL((k_reset<false>), grid, block, h->lds_bytes, s, h->P, mask, (uint8_t *)records_out, raw_out, h->raw_stride, 0);
   HIPCHK(hipGetLastError());
   if ((rc = start_deals(h, s))) return rc;  // refill what was taken (one episode per game and cycle)
   return publish_deals(h, s);
@@ -878,14 +888,14 @@ int skyjo_vec_reset(skyjo_vec *h, const uint8_t *mask, void *records_out, void *
   if (!h) return fail(SKYJO_E_INVALID, "null handle");
   GUARD(h);
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
-  return reset_impl(h, mask, records_out, (hipStream_t)stream, nullptr);
+  return reset_impl(h, mask, records_out, (hipStream_t)stream, nullptr, h->rec_planar_all ? 1 : 0);
 }
 
 static int step_once(skyjo_vec *h, const int32_t *actions, void *records_out, double *end_rew, uint8_t *end_flag, hipStream_t s,
-                     uint8_t *raw_out = nullptr) {
+                     uint8_t *raw_out = nullptr, bool planar_out = false) {
   const bool due = h->pending_iters + 1 >= h->deal_every_iters, piped = piped_mode(h);
   if (due && piped) plan_cycle(h);
-  int rc = launch_step(h, s, false, actions, (uint8_t *)records_out, nullptr, 1, 0, end_rew, end_flag, raw_out);
+  int rc = launch_step(h, s, false, actions, (uint8_t *)records_out, nullptr, 1, 0, end_rew, end_flag, raw_out, 0, planar_out && records_out);
   if (rc) return rc;
   if (due) return piped ? start_deals_piped(h, s) : start_deals(h, s);
   return SKYJO_OK;
@@ -895,7 +905,7 @@ int skyjo_vec_step(skyjo_vec *h, const int32_t *actions, void *records_out, void
   if (!h || !actions) return fail(SKYJO_E_INVALID, "null argument");
   GUARD(h);
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
-  return step_once(h, actions, records_out, nullptr, nullptr, (hipStream_t)stream);
+  return step_once(h, actions, records_out, nullptr, nullptr, (hipStream_t)stream, nullptr, h->rec_planar_all);
 }
 
 int skyjo_vec_step_collect(skyjo_vec *h, const int32_t *actions, void *records_out, double *final_rewards_out,
@@ -903,7 +913,7 @@ int skyjo_vec_step_collect(skyjo_vec *h, const int32_t *actions, void *records_o
   if (!h || !actions || !final_rewards_out || !episode_end_out) return fail(SKYJO_E_INVALID, "null argument");
   GUARD(h);
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
-  return step_once(h, actions, records_out, final_rewards_out, episode_end_out, (hipStream_t)stream);
+  return step_once(h, actions, records_out, final_rewards_out, episode_end_out, (hipStream_t)stream, nullptr, h->rec_planar_all);
 }
 
 // ---- config 5's collection loop (include/skyjo_vec.h: skyjo_vec_model_rollout) ----
@@ -924,23 +934,25 @@ static int model_check(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_ve
 static int model_iter(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, int t, uint64_t seed, uint64_t first_ticket,
                       int32_t no_masking, const skyjo_vec_rollout_buffers *b, hipStream_t s) {
   const size_t B = (size_t)h->P.B, rb = (size_t)h->P.L.rec_bytes, N = (size_t)h->P.L.N, vd = value ? (size_t)value->net.out_dim : 0;
+  const bool planar = h->rec_planar_all;        // (SKYJO_REC_TILE_PLANAR_ALL: an iteration's records are tiles * 64 slots, piece-planar)
+  const size_t per_it = (planar ? h->G : B) * rb;
   uint8_t *rec = (uint8_t *)b->records;
   SkMlpDraw d{};
   d.enable = 1, d.mask_offset = h->P.L.Dp, d.no_masking = no_masking, d.seed = seed, d.ticket = first_ticket + (uint64_t)t;
   d.game_id0 = h->P.game_id0, d.actions = b->actions + (size_t)t * B, d.logp = b->logp ? b->logp + (size_t)t * B : nullptr;
-  int rc = launch_mlp(policy, value ? value : policy, value ? 2 : 1, rec + (size_t)t * B * rb, (int)rb, policy->obs_dim, (int64_t)B, nullptr, d,
-                      value ? b->values + (size_t)t * B * vd : nullptr, s, h);
+  int rc = launch_mlp(policy, value ? value : policy, value ? 2 : 1, rec + (size_t)t * per_it, (int)rb, policy->obs_dim, (int64_t)B, nullptr, d,
+                      value ? b->values + (size_t)t * B * vd : nullptr, s, h, planar ? 1 : 0);
   if (rc) return rc;
-  return step_once(h, b->actions + (size_t)t * B, rec + (size_t)(t + 1) * B * rb, b->final_rewards ? b->final_rewards + (size_t)t * B * N : nullptr,
-                   b->episode_end ? b->episode_end + (size_t)t * B : nullptr, s);
+  return step_once(h, b->actions + (size_t)t * B, rec + (size_t)(t + 1) * per_it, b->final_rewards ? b->final_rewards + (size_t)t * B * N : nullptr,
+                   b->episode_end ? b->episode_end + (size_t)t * B : nullptr, s, nullptr, planar);
 }
 // the bootstrap value of the records a rollout ends on
 static int model_tail(skyjo_vec *h, const skyjo_vec_mlp *value, int T, const skyjo_vec_rollout_buffers *b, hipStream_t s) {
   if (!value) return SKYJO_OK;
   const size_t B = (size_t)h->P.B, rb = (size_t)h->P.L.rec_bytes, vd = (size_t)value->net.out_dim;
   SkMlpDraw nodraw{};
-  return launch_mlp(value, value, 1, (const uint8_t *)b->records + (size_t)T * B * rb, (int)rb, value->obs_dim, (int64_t)B, b->values + (size_t)T * B * vd,
-                    nodraw, nullptr, s);
+  return launch_mlp(value, value, 1, (const uint8_t *)b->records + (size_t)T * (h->rec_planar_all ? h->G : B) * rb, (int)rb, value->obs_dim, (int64_t)B,
+                    b->values + (size_t)T * B * vd, nodraw, nullptr, s, nullptr, h->rec_planar_all ? 1 : 0);
 }
 
 int skyjo_vec_model_rollout(skyjo_vec *h, const skyjo_vec_mlp *policy, const skyjo_vec_mlp *value, int32_t T, uint64_t seed,
@@ -996,18 +1008,21 @@ int skyjo_vec_rollout(skyjo_vec *h, int32_t iters, uint64_t policy_seed, void *r
   return SKYJO_OK;
 }
 
-int skyjo_vec_observe(skyjo_vec *h, const int32_t *players, void *records_out, void *stream) {
+static int observe_impl(skyjo_vec *h, const int32_t *players, void *records_out, void *stream, int planar) {
   if (!h || !records_out) return fail(SKYJO_E_INVALID, "null argument");
   GUARD(h);
   if (!h->seeded) return fail(SKYJO_E_STATE, "skyjo_vec_seed must be called first");
   dim3 grid(h->P.tiles), block(SK_TILE);
   hipStream_t s = (hipStream_t)stream;
   if (h->P.L.indirect)
-    hipLaunchKernelGGL((k_observe<true>), grid, block, h->lds_bytes, s, h->P, players, (uint8_t *)records_out);
+    hipLaunchKernelGGL((k_observe<true>), grid, block, h->lds_bytes, s, h->P, players, (uint8_t *)records_out, planar);
   else
-    hipLaunchKernelGGL((k_observe<false>), grid, block, h->lds_bytes, s, h->P, players, (uint8_t *)records_out);
+    hipLaunchKernelGGL((k_observe<false>), grid, block, h->lds_bytes, s, h->P, players, (uint8_t *)records_out, 0);
   HIPCHK(hipGetLastError());
   return SKYJO_OK;
+}
+int skyjo_vec_observe(skyjo_vec *h, const int32_t *players, void *records_out, void *stream) {
+  return observe_impl(h, players, records_out, stream, h && h->rec_planar_all ? 1 : 0);
 }
 
 static int unpack_impl(skyjo_vec *h, const void *records, int64_t n, int8_t *obs, int8_t *mask, uint8_t *agent, uint8_t *phase, uint8_t *done,
@@ -1487,7 +1502,7 @@ int skyjo_vec_get_option(const skyjo_vec *h, int option, int64_t *value_out) {
     case SKYJO_OPT_DEAL_INTERVAL: *value_out = h->deal_every_iters; return SKYJO_OK;
     case SKYJO_OPT_OVERLAP: *value_out = h->merged ? 3 : h->overlap ? 2 : 0; return SKYJO_OK;
     case SKYJO_OPT_NO_BANK: *value_out = h->no_bank ? 1 : 0; return SKYJO_OK;
-    case SKYJO_OPT_RECORD_LAYOUT: *value_out = h->rec_planar ? SKYJO_REC_TILE_PLANAR : SKYJO_REC_ROW_MAJOR; return SKYJO_OK;
+    case SKYJO_OPT_RECORD_LAYOUT: *value_out = h->rec_planar_all ? SKYJO_REC_TILE_PLANAR_ALL : h->rec_planar ? SKYJO_REC_TILE_PLANAR : SKYJO_REC_ROW_MAJOR; return SKYJO_OK;
     case SKYJO_OPT_INLINE_WORK_LIST: *value_out = h->fused_scan ? 0 : 1; return SKYJO_OK;
     case SKYJO_OPT_UNPIPELINED: *value_out = h->piped ? 0 : 1; return SKYJO_OK;
     case SKYJO_OPT_CYCLE_S: *value_out = h->cycle_s; return SKYJO_OK;
@@ -1523,10 +1538,14 @@ int skyjo_vec_set_option(skyjo_vec *h, int option, int64_t value) {
       h->no_bank = value != 0;
       return SKYJO_OK;
     case SKYJO_OPT_RECORD_LAYOUT:
-      if (value != SKYJO_REC_ROW_MAJOR && value != SKYJO_REC_TILE_PLANAR) return fail(SKYJO_E_INVALID, "SKYJO_OPT_RECORD_LAYOUT takes SKYJO_REC_ROW_MAJOR or SKYJO_REC_TILE_PLANAR");
-      if (value == SKYJO_REC_TILE_PLANAR && !h->merged_capable)
+      if (value != SKYJO_REC_ROW_MAJOR && value != SKYJO_REC_TILE_PLANAR && value != SKYJO_REC_TILE_PLANAR_ALL)
+        return fail(SKYJO_E_INVALID, "SKYJO_OPT_RECORD_LAYOUT takes SKYJO_REC_ROW_MAJOR, SKYJO_REC_TILE_PLANAR or SKYJO_REC_TILE_PLANAR_ALL");
+      if (value != SKYJO_REC_ROW_MAJOR && !h->merged_capable)
         return fail(SKYJO_E_INVALID, "the tile-planar record layout exists for the one-kernel form of the fused rollout (two to four players)");
-      h->rec_planar = value == SKYJO_REC_TILE_PLANAR;
+      if (value == SKYJO_REC_TILE_PLANAR_ALL && !h->P.L.indirect)
+        return fail(SKYJO_E_INVALID, "SKYJO_REC_TILE_PLANAR_ALL: reset / observe / step write tile-planar records of the indirect observation only");
+      h->rec_planar = value != SKYJO_REC_ROW_MAJOR;
+      h->rec_planar_all = value == SKYJO_REC_TILE_PLANAR_ALL;
       return SKYJO_OK;
     case SKYJO_OPT_INLINE_WORK_LIST:
       h->fused_scan = value == 0;
@@ -1619,7 +1638,7 @@ int skyjo_vec_observe_host(skyjo_vec *h, const int32_t *players_host, void *reco
   GUARD(h);
   if (h->fast_host) {  // (the games do not change: a valid host copy of them stays valid)
     if (players_host) memcpy(h->hm_actions, players_host, sizeof(int32_t) * (size_t)h->P.B);
-    int rc = skyjo_vec_observe(h, players_host ? h->hm_actions_d : nullptr, h->hm_records_d, nullptr);
+    int rc = observe_impl(h, players_host ? h->hm_actions_d : nullptr, h->hm_records_d, nullptr, 0);  // (host-style records are row-major whatever the option)
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(nullptr));
     memcpy(records_out_host, h->hm_records, (size_t)h->P.B * h->P.L.rec_bytes);
@@ -1629,7 +1648,7 @@ int skyjo_vec_observe_host(skyjo_vec *h, const int32_t *players_host, void *reco
   if (rc) return rc;
   if (players_host)
     HIPCHK(hipMemcpy(h->d_actions, players_host, sizeof(int32_t) * (size_t)h->P.B, hipMemcpyHostToDevice));
-  if ((rc = skyjo_vec_observe(h, players_host ? h->d_actions : nullptr, h->d_records, nullptr))) return rc;
+  if ((rc = observe_impl(h, players_host ? h->d_actions : nullptr, h->d_records, nullptr, 0))) return rc;
   HIPCHK(hipMemcpy(records_out_host, h->d_records, (size_t)h->P.B * h->P.L.rec_bytes, hipMemcpyDeviceToHost));
   return dev_error_check(h);
 }

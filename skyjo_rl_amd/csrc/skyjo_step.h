@@ -436,18 +436,35 @@ __device__ __forceinline__ void step_body(const SkParams &Pin, const int tile, c
   TRACE_STORE(0, (uint32_t)(iter0 / (uint64_t)(iters > 0 ? iters : 1)), lane, tile);
 }
 
-template <bool INDIRECT, bool POLICY, int NP>
+template <bool INDIRECT, bool POLICY, int NP, bool PLANAR = false>
 __global__ __launch_bounds__(SK_TILE) void k_step(SkParams Pin, const int32_t *actions, uint8_t *rec_out,
                                                   int32_t *act_out, int iters, uint64_t policy_seed, uint64_t iter0,
                                                   double *end_rew_out, uint8_t *end_out, uint8_t *raw_out, int raw_stride) {
   extern __shared__ uint32_t lds_raw[];
-  step_body<INDIRECT, POLICY, NP>(Pin, (int)blockIdx.x, (int)threadIdx.x, lds_raw, actions, rec_out, act_out, iters, policy_seed, iter0,
-                                  end_rew_out, end_out, raw_out, raw_stride);
+  step_body<INDIRECT, POLICY, NP, PLANAR>(Pin, (int)blockIdx.x, (int)threadIdx.x, lds_raw, actions, rec_out, act_out, iters, policy_seed, iter0,
+                                          end_rew_out, end_out, raw_out, raw_stride);
+}
+
+// One record of the indirect observation into rec_out in either layout (k_observe, k_reset: `planar` - SKYJO_REC_TILE_PLANAR_ALL -
+// puts piece p of lane l's record at tile block + p * 1024 + l * 16, like the fused rollout's).
+template <bool INDIRECT>
+__device__ __forceinline__ void sk_emit_to(const SkParams &P, uint8_t *lp, const HdrRegs &h, const ObsRegs &ob, uint8_t *rec_out, int tile, int lane,
+                                           int planar) {
+  const int g = tile * SK_TILE + lane;
+  if (INDIRECT && planar) {
+    uint4 rr[4];
+    emit_record<INDIRECT>(P, lp, h, ob, -1, nullptr, rr);
+    uint4 *o = (uint4 *)(rec_out + (size_t)tile * SK_TILE * P.L.rec_bytes) + lane;
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k * SK_TILE] = rr[k];
+  } else {
+    emit_record<INDIRECT>(P, lp, h, ob, -1, rec_out + (size_t)g * P.L.rec_bytes);
+  }
 }
 
 // SimpleSkyjoEnv.observe(agent) (skyjo_env.py:199-214) for arbitrary players; state untouched.
 template <bool INDIRECT>
-__global__ __launch_bounds__(SK_TILE) void k_observe(SkParams P, const int32_t *players, uint8_t *rec_out) {
+__global__ __launch_bounds__(SK_TILE) void k_observe(SkParams P, const int32_t *players, uint8_t *rec_out, int planar) {
   extern __shared__ uint32_t lds_raw[];
   const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 16;
@@ -460,12 +477,12 @@ __global__ __launch_bounds__(SK_TILE) void k_observe(SkParams P, const int32_t *
   q = q < 0 ? 0 : (q >= P.L.N ? P.L.N - 1 : q);
   ObsRegs ob;
   obs_load(P, lp, q, ob);
-  emit_record<INDIRECT>(P, lp, h, ob, -1, rec_out + (size_t)g * P.L.rec_bytes);
+  sk_emit_to<INDIRECT>(P, lp, h, ob, rec_out, tile, lane, planar);
 }
 
 // SkyjoGame.reset for the masked games: take the pre-dealt episode.
 template <bool INDIRECT>
-__global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *mask, uint8_t *rec_out, uint8_t *raw_out, int raw_stride) {
+__global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *mask, uint8_t *rec_out, uint8_t *raw_out, int raw_stride, int planar) {
   extern __shared__ uint32_t lds_raw[];
   const int tile = blockIdx.x, lane = threadIdx.x, g = tile * SK_TILE + lane;
   uint8_t *lp = (uint8_t *)lds_raw + lane * 16;
@@ -486,7 +503,7 @@ __global__ __launch_bounds__(SK_TILE) void k_reset(SkParams P, const uint8_t *ma
   if (rec_out) {
     ObsRegs ob;
     obs_load(P, lp, LB(H_PLAYER), ob);
-    emit_record<INDIRECT>(P, lp, h, ob, -1, rec_out + (size_t)g * P.L.rec_bytes);
+    sk_emit_to<INDIRECT>(P, lp, h, ob, rec_out, tile, lane, planar);
   }
   if (want) tile_store(P, P.state, tile, lane, lp);
   if (raw_out && (LB(H_FLAGS) & F_VALID)) sk_export_raw(P, lp, g, raw_out + (size_t)g * raw_stride);

@@ -23,7 +23,10 @@ class RolloutBuffer:
         B, N = env.num_envs, env.num_players
         self.T, self.B, self.N = T, B, N
         self._env = env
-        self.records = env.new_records(T + 1)                    # records[t] = what the actor of step t saw; [T] = bootstrap
+        # records[t] = what the actor of step t saw; [T] = bootstrap.  With the engine's layout 'tile-planar-all' the buffer is tile-planar
+        # ([T + 1, tiles, P, 64, 16]: the step kernel writes it from registers, the nets read it in place) and ``views`` copies
+        self.planar = env.record_layout == "tile-planar-all"
+        self.records = env.new_planar_records(T + 1) if self.planar else env.new_records(T + 1)
         self.actions = torch.empty((T, B), dtype=torch.int32, device=dev)
         self.logp = torch.empty((T, B), dtype=torch.float32, device=dev)
         self.values = torch.empty((T + 1, B, 1), dtype=torch.float32, device=dev)
@@ -33,7 +36,8 @@ class RolloutBuffer:
     def views(self, env=None):
         """Zero-copy column views of the stored records: observations int8 [T+1, B, D], action_mask int8 [T+1, B, 26],
         agent / phase / done / status uint8 [T+1, B]."""
-        return (env or self._env).split(self.records)
+        e = env or self._env
+        return e.split(e.rows_from_planar(self.records) if self.planar else self.records)
 
     @property
     def valid(self):
@@ -70,9 +74,9 @@ def collect_stepwise(env, policy, value, buf, seed=0, first_ticket=0, first_reco
     _first(env, buf, first_records)
     for t in range(buf.T):
         policy.act(env, buf.records[t], seed=seed, ticket=first_ticket + t, actions=buf.actions[t], logp=buf.logp[t],
-                   value_net=value, values=buf.values[t])
+                   value_net=value, values=buf.values[t], planar=buf.planar)
         # a game that ends in this step has its flag and its final rewards written by the step kernel itself
         _lib.check(L.skyjo_vec_step_collect(env._h, vp(buf.actions[t]), vp(buf.records[t + 1]), vp(buf.final_rewards[t]),
                                             vp(buf.episode_end[t]), env._stream()))
-    value(buf.records[buf.T], out=buf.values[buf.T])
+    value(buf.records[buf.T], out=buf.values[buf.T], planar=buf.planar)
     return buf

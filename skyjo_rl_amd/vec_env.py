@@ -119,24 +119,32 @@ class SkyjoVecEnv:
         return (self.num_envs + 63) // 64
 
     def set_record_layout(self, layout):
-        """'row-major' (default) or 'tile-planar' (include/skyjo_vec.h: SKYJO_OPT_RECORD_LAYOUT): how ``rollout`` lays out its
-        records.  Tile-planar records come as ``new_planar_records(iters)`` = uint8 [iters, tiles, record_bytes / 16, 64, 16];
+        """'row-major' (default), 'tile-planar' or 'tile-planar-all' (include/skyjo_vec.h: SKYJO_OPT_RECORD_LAYOUT): how ``rollout`` - and
+        with '-all' ``reset`` / ``observe`` / ``step`` / the model rollout as well - lays out its records.  Tile-planar records come as
+        ``new_planar_records(iters)`` = uint8 [iters, tiles, record_bytes / 16, 64, 16] (one iteration: ``new_planar_records()``);
         ``FusedNet`` / ``sample_actions`` / ``episode_ends`` read them in place (``planar=True``)."""
         _lib.check(self._L.skyjo_vec_set_option(self._h, _lib.OPT_RECORD_LAYOUT,
-                                                {"row-major": _lib.REC_ROW_MAJOR, "tile-planar": _lib.REC_TILE_PLANAR}[layout]))
+                                                {"row-major": _lib.REC_ROW_MAJOR, "tile-planar": _lib.REC_TILE_PLANAR,
+                                                 "tile-planar-all": _lib.REC_TILE_PLANAR_ALL}[layout]))
 
     @property
     def record_layout(self):
         """The layout ``rollout`` writes, as the engine has it (SKYJO_OPT_RECORD_LAYOUT)."""
         v = C.c_int64()
         _lib.check(self._L.skyjo_vec_get_option(self._h, _lib.OPT_RECORD_LAYOUT, C.byref(v)))
-        return "tile-planar" if v.value == _lib.REC_TILE_PLANAR else "row-major"
+        return {_lib.REC_ROW_MAJOR: "row-major", _lib.REC_TILE_PLANAR: "tile-planar", _lib.REC_TILE_PLANAR_ALL: "tile-planar-all"}[int(v.value)]
 
-    def new_planar_records(self, iters):
-        return self._torch().empty((iters, self.tiles, self.record_bytes // 16, 64, 16), dtype=self._torch().uint8, device=self._dev())
+    def _new_step_records(self):
+        """One iteration's records in the layout ``reset`` / ``observe`` / ``step`` write."""
+        return self.new_planar_records() if self.record_layout == "tile-planar-all" else self.new_records()
+
+    def new_planar_records(self, *iters):
+        return self._torch().empty((*iters, self.tiles, self.record_bytes // 16, 64, 16), dtype=self._torch().uint8, device=self._dev())
 
     def rows_from_planar(self, records):
         """Row-major copy [iters, num_envs, record_bytes] of tile-planar records (``split`` / ``unpack`` take it from there)."""
+        if records.dim() == 4:  # one iteration
+            return records.permute(0, 2, 1, 3).reshape(records.shape[0] * 64, self.record_bytes)[:self.num_envs]
         it, t = records.shape[0], records.shape[1]
         return records.permute(0, 1, 3, 2, 4).reshape(it, t * 64, self.record_bytes)[:, :self.num_envs]
 
@@ -177,7 +185,7 @@ class SkyjoVecEnv:
 
     def reset(self, mask=None, out=None):
         torch = self._torch()
-        out = self.new_records() if out is None else out
+        out = self._new_step_records() if out is None else out
         mp = None
         if mask is not None:
             mask = mask.to(device=self._dev(), dtype=torch.uint8).contiguous()
@@ -190,7 +198,7 @@ class SkyjoVecEnv:
         torch = self._torch()
         assert actions.is_cuda and actions.dtype == torch.int32 and actions.is_contiguous()
         assert actions.numel() == self.num_envs
-        out = self.new_records() if out is None else out
+        out = self._new_step_records() if out is None else out
         _lib.check(self._L.skyjo_vec_step(self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(out.data_ptr()),
                                           self._stream()))
         return out
@@ -203,7 +211,7 @@ class SkyjoVecEnv:
         rp = C.c_void_p(records.data_ptr()) if records is not None else None
         ap = C.c_void_p(actions.data_ptr()) if actions is not None else None
         if records is not None:
-            planar = self.record_layout == "tile-planar"
+            planar = self.record_layout != "row-major"
             per_it = self.tiles * 64 if planar else self.num_envs
             assert records.is_contiguous() and records.numel() == iters * per_it * self.record_bytes
         if actions is not None:
@@ -211,7 +219,7 @@ class SkyjoVecEnv:
         _lib.check(self._L.skyjo_vec_rollout(self._h, int(iters), int(policy_seed), rp, ap, self._stream()))
 
     def observe(self, players=None, out=None):
-        out = self.new_records() if out is None else out
+        out = self._new_step_records() if out is None else out
         pp = C.c_void_p(players.data_ptr()) if players is not None else None
         _lib.check(self._L.skyjo_vec_observe(self._h, pp, C.c_void_p(out.data_ptr()), self._stream()))
         return out

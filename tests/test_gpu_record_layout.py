@@ -122,3 +122,43 @@ def test_the_consumers_read_tile_planar_records_in_place(B, N, precision):
             ends += int(ee.sum())
     assert ends > 0  # (some of the sampled iterations ended episodes: the columns are not trivially equal)
     pol.close(), val.close(), env.close()
+
+
+@pytest.mark.parametrize("B,N,precision", [(4106, 3, "bf16"), (8192, 4, "fp32")])
+def test_a_model_rollout_that_never_holds_a_row_major_record(B, N, precision):
+    """SKYJO_REC_TILE_PLANAR_ALL: reset / observe / step_collect / skyjo_vec_model_rollout write tile-planar records too (the step kernel
+    from the registers the record was assembled in), the nets read them in place: every column of the rollout buffer - actions,
+    log-probabilities, values, episode ends, final rewards - and every record equal the row-major engine's, bit for bit; so does the
+    same loop made one launch at a time."""
+    import torch
+    from skyjo_rl_amd import SkyjoVecEnv
+    from skyjo_rl_amd.action_mask_model import ActionMaskModel, FusedNet
+    from skyjo_rl_amd.rollout import RolloutBuffer, collect, collect_stepwise
+
+    torch.manual_seed(9)
+    T = 48
+    model = ActionMaskModel(obs_dim=31).cuda()
+    pol, val = FusedNet(model.policy, precision=precision), FusedNet(model.value, precision=precision)
+    bufs = []
+    for layout, stepwise in (("row-major", False), ("tile-planar-all", False), ("tile-planar-all", True)):
+        env = SkyjoVecEnv(B, num_players=N, auto_reset=True)
+        env.set_record_layout(layout)
+        assert env.record_layout == layout
+        env.seed(None, 77)
+        first = env.reset()
+        assert tuple(first.shape) == ((env.tiles, env.record_bytes // 16, 64, 16) if layout != "row-major" else (B, env.record_bytes))
+        buf = RolloutBuffer(env, T)
+        for r in range(3):
+            (collect_stepwise if stepwise else collect)(env, pol, val, buf, seed=3, first_ticket=r * T, first_records=first if r == 0 else buf.records[T].clone())
+        rows = env.rows_from_planar(buf.records) if buf.planar else buf.records
+        bufs.append((rows.clone(), buf.actions.clone(), buf.logp.clone(), buf.values.clone(), buf.episode_end.clone(), buf.final_rewards.clone(),
+                     env.observe() if not buf.planar else env.rows_from_planar(env.observe()), env.counters()))
+        env.close()
+    ref = bufs[0]
+    assert int(ref[4].sum()) > 0 and ref[7]["episodes"] > 0
+    for other in bufs[1:]:
+        for k in range(7):
+            assert torch.equal(ref[k], other[k]), k
+        for k in ("steps", "episodes", "resets", "sum_len", "illegal"):
+            assert ref[7][k] == other[7][k]
+    pol.close(), val.close()
