@@ -15,7 +15,7 @@ UNITS = [("skyjo_capi", os.path.join(CSRC, "skyjo_capi.hip"), ["-mllvm", "-amdgp
 SRC = UNITS[0][1]
 DEPS = [u[1] for u in UNITS] + HEADERS
 OUT = os.path.join(HERE, "libskyjo_vec.so")
-OBJ_DIR = os.path.join(HERE, "build")
+OBJ_DIR = os.path.join(HERE, "_obj")  # (object files of the two units; git-ignored, not sent to the GPU box)
 
 # -ffp-contract=off: rewards are float64 and must round exactly like numpy (no fused multiply-add); the policy unit shares the
 # masked draw's float32 arithmetic with the environment unit (skyjo_draw.h) and must round like it

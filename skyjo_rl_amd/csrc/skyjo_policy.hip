@@ -11,14 +11,16 @@
 // exactly the per-lane fragments the kernel loads (one 16-byte load per lane and MFMA).
 // Lane maps (gfx950): A[row l&31][k = 8(l>>5)+j], B[k = 8(l>>5)+j][col l&31], C[row (r&3)+8(r>>2)+4(l>>5)][col l&31].
 //
-// Round 6: what the counters said about the round-2 kernels (profiles/r6_cfg5_pmc.json: the matrix pipe busy 27 % / 41 % of the
-// time, the vector ALU 51 % / 37 %, both at once 15 % / 6 %) is that a wavefront did its MFMAs and its activations in turn,
-// and that the workgroup's barriers kept the two wavefronts of a SIMD in the same phase - the two pipes took turns.  Here every
+// Round 6: what the counters said about the round-2 kernels (profiles/r6_cfg5_pmc_round2_kernels.json: the matrix pipe busy 26 % / 43 % of
+// the kernel, the vector ALU 50 % / 38 %, both at once 15 % / 7 %) is that a wavefront did its MFMAs and its activations in turn, and
+// that the workgroup's barriers kept the two wavefronts of a SIMD in the same phase - the two pipes took turns.  Here every
 // wavefront runs a software pipeline of its own: the 16 (48) MFMAs of output tile u + 1 are issued between the activations of
-// tile u (one `tanh` per MFMA gap: v_fma, v_exp, v_add, v_rcp, v_fma + half a v_cvt_pk = 30 issue cycles against the MFMA's 32),
-// layer 3 rides behind (two MFMAs per tile) and layer 2's first chain runs inside layer 1's activations.  The weights of the
-// 256 x 256 layer arrive by LDS-DMA (no registers, no LDS-write instructions) behind the first layer; a workgroup keeps them for
-// `passes` batches of 256 games, so that a 65 536-game launch is ONE round of 256 workgroups.
+// tile u (one `tanh` per MFMA gap: v_exp, v_add, v_rcp, v_fma + half a v_cvt_pk = 26.5 issue cycles against the MFMA's 32 - the
+// factor 2 / ln 2 is in the packed weights, the bias is the accumulator's initial value), layer 3 rides behind (two MFMAs per
+// tile) and - float32-grade - layer 2's first chain runs inside layer 1's activations.  The weights of the 256 x 256 layer travel
+// into LDS THROUGH REGISTERS (LDS-DMA needs none, but a piece costs the issuing wavefront 100 - 180 cycles, lands slowly, and every
+// other vector-memory operation of the wavefront queues behind it: EXPERIMENTS.md round 6); a workgroup keeps them for `passes`
+// batches of 256 games, so that a 65 536-game launch is ONE round of 256 workgroups.
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,7 +33,7 @@ typedef float skp_f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t skp_u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) float *skp_lds_f32;  // (an LDS pointer that stays one: ds_read, not flat_load)
 #define SKP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-#define SKP_LDS32(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(p))
+#define SKP_LDS32(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(p))  // the LDS offset of a __shared__ object
 
 __device__ __forceinline__ skp_bf16x8 skp_frag(const uint4 *p) {
   const uint4 q = *p;
@@ -150,28 +152,6 @@ struct SkMlpArgs {
   int passes;
 };
 
-// LDS-DMA of 4 KB: four global_load_lds_dwordx4, each 64 lanes x 16 bytes, memory  base + voff + k * 1024  ->  LDS  lds + k * 1024
-// + lane * 16  (the immediate offset applies to both sides; M0 holds the LDS base and is restored).
-__device__ __forceinline__ void skp_dma4k(const uint8_t *base, uint32_t voff, uint32_t lds) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-               "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-               "s_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(base), "s"(lds)
-               : "memory");
-}
-__device__ __forceinline__ void skp_dma2k(const uint8_t *base, uint32_t voff, uint32_t lds) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-               "s_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(base), "s"(lds)
-               : "memory");
-}
-__device__ __forceinline__ void skp_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Two activated values -> one register of a bf16 fragment (v_cvt_pk_bf16_f32)
 typedef __bf16 skp_bf16x2 __attribute__((ext_vector_type(2)));
@@ -198,7 +178,6 @@ __device__ __forceinline__ skp_bf16x8 skp_frag4(const uint32_t (&w)[4]) {
 // of the gap that consumes it and at the end of the gap that produced it.  The pins and the barriers are ordered among
 // themselves, so an operation sits between its input's pin and its output's.  No instruction is emitted for a pin.
 #define SKP_PIN(v) asm volatile("" : "+v"(v))
-#define SKP_PIN_S(v) asm volatile("" : "+s"(v))
 struct SkpAct {
   float e[16], r[16];
   uint32_t w[8];
