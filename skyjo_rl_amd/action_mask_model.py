@@ -6,7 +6,7 @@ default fully connected net (two tanh layers of 256 units, separate value branch
 consumes the zero-copy views of the engine's record tensor directly on the GPU (``SkyjoVecEnv.split``),
 so a PPO-style rollout never leaves the device.  ``ActionMaskModel`` / ``sample_actions`` are the plain-torch
 statement of the model (float32) and the test reference.  Behind the C ABI the same model runs as hand-written
-gfx950 kernels: ``FusedNet`` packs one branch for the matrix cores (``skyjo_vec_mlp_*``, csrc/skyjo_policy.h: float32-grade
+gfx950 kernels: ``FusedNet`` packs one branch for the matrix cores (``skyjo_vec_mlp_*``, csrc/skyjo_policy.hip: float32-grade
 by default - bf16-pair operands, float32 accumulation, within 1e-4 of the float32 module - or plain bf16 operands as the
 fast mode; tolerances in tests/test_gpu_policy_net.py), ``FusedNet.act`` adds the masking + categorical draw in the net's epilogue, and with
 ``value_net=`` the value branch rides in the same launch (``skyjo_vec_mlp_act_value``).
@@ -67,7 +67,7 @@ def sample_actions_fused(model, env, records, seed=0, ticket=0, logp=None):
 
 class FusedNet:
     """One branch of the model (``model.policy`` or ``model.value``: Linear-Tanh-Linear-Tanh-Linear with 256 hidden
-    units) packed for the MI355X matrix cores (``skyjo_vec_mlp_*``, csrc/skyjo_policy.h): weights as bf16 MFMA
+    units) packed for the MI355X matrix cores (``skyjo_vec_mlp_*``, csrc/skyjo_policy.hip): weights as bf16 MFMA
     fragments (pairs of them in the float32-grade mode), float32 accumulation, observations read straight from the
     engine's records."""
 

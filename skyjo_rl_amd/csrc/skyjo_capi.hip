@@ -159,7 +159,7 @@ struct skyjo_vec {
   int arena_mode = 0;  // 1: adding up, 2: carving
   // optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
   bool profile = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[SKYJO_PROF_KERNELS];  // k_step, k_scan, k_deal, k_publish, k_mlp_forward*
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[SKYJO_PROF_KERNELS];  // k_step, k_scan, k_deal, k_publish, k_net_*
 };
 
 struct skyjo_vec_snapshot {

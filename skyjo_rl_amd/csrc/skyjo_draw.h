@@ -23,7 +23,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 
 // One game's draw: masked = logits + clamp(log(mask), FLOAT_MIN) (action_mask_model.py:70-71), softmax, inverse CDF of
-// the Philox uniform of (seed, ticket, game).  Shared by k_sample and by the policy net's epilogue (skyjo_policy.h).
+// the Philox uniform of (seed, ticket, game).  Shared by k_sample and by the policy net's epilogue (skyjo_policy.hip).
 __device__ __forceinline__ int sk_draw_action(const float *row, const uint32_t *mw, int no_masking, uint64_t seed, uint64_t ticket,
                                               uint64_t gid, float *logp_out, float *uniform_out) {
   const float FLOAT_MIN = -3.4028234663852886e38f;  // torch.finfo(float32).min == ray's FLOAT_MIN

@@ -1,4 +1,4 @@
-"""the policy net of config 5 on the matrix cores (skyjo_vec_mlp_forward, csrc/skyjo_policy.h)
+"""the policy net of config 5 on the matrix cores (skyjo_vec_mlp_forward, csrc/skyjo_policy.hip)
 against torch.  The reference's TorchFC is float32 (rlskyjo/models/action_mask_model.py:43-49, 58-74); north_star
 states no tolerance, the ones used here are written out:
 
