@@ -1089,6 +1089,12 @@ int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, in
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
   };
+  auto bf16_to_float = [](uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+  };
   auto bf16_lo = [&](float f) {  // what the high half leaves over, again rounded to bf16: f = hi + lo to 16 significant bits
     const uint32_t hi = (uint32_t)bf16(f) << 16;
     float fh;
@@ -1118,7 +1124,8 @@ int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, in
         for (int j = 0; j < 8; j++) {
           const float v = SKP_SCALE * w2[(size_t)m * H + acc_k(ks, hh, j)];
           const size_t at = (((size_t)u * 16 + ks) * 64 + l) * 8 + j;
-          f2[at] = bf16(v);
+          // bf16 mode: the layer takes r = (1 - tanh) / 2 of the layer before: - 2 W as weights (exact: a power of two), W 1 joins the bias
+          f2[at] = split ? bf16(v) : bf16(-2.0f * v);
           if (split) g2[at] = bf16_lo(v);
         }
     }
@@ -1128,15 +1135,23 @@ int skyjo_vec_mlp_create(int32_t device_id, int32_t obs_dim, int32_t out_dim, in
       for (int j = 0; j < 8; j++) {
         const float v = m < out_dim ? w3[(size_t)m * H + acc_k(ks, hh, j)] : 0.f;
         const size_t at = ((size_t)ks * 64 + l) * 8 + j;
-        f3[at] = bf16(v);
+        f3[at] = split ? bf16(v) : bf16(-2.0f * v);
         if (split) g3[at] = bf16_lo(v);
       }
     for (int r = 0; r < 16; r++) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      c3[(size_t)l * 16 + r] = row < out_dim ? b3[row] : 0.f;
+      double b = row < out_dim ? (double)b3[row] : 0.0;
+      if (!split && row < out_dim)  // (+ W 1 with the weights as they are stored: bf16-rounded)
+        for (int k = 0; k < H; k++) b += (double)bf16_to_float(bf16(w3[(size_t)row * H + k]));
+      c3[(size_t)l * 16 + r] = (float)b;
     }
   }
-  for (int u = 0; u < H; u++) c2[u] = SKP_SCALE * b2[u];  // (enters the activation's first multiply-add: skyjo_policy.hip)
+  for (int u = 0; u < H; u++) {  // (bf16: the accumulator's initial value; float32-grade: the addend in front of the exponential - skyjo_policy.hip)
+    double b = (double)(SKP_SCALE * b2[u]);
+    if (!split)
+      for (int k = 0; k < H; k++) b += (double)bf16_to_float(bf16(SKP_SCALE * w2[(size_t)u * H + k]));
+    c2[u] = (float)b;
+  }
   skyjo_vec_mlp *m = new skyjo_vec_mlp();
   m->device_id = device_id, m->obs_dim = obs_dim;
   struct Piece { const void *src; size_t bytes; };

@@ -15,8 +15,8 @@
 // the kernel, the vector ALU 50 % / 38 %, both at once 15 % / 7 %) is that a wavefront did its MFMAs and its activations in turn, and
 // that the workgroup's barriers kept the two wavefronts of a SIMD in the same phase - the two pipes took turns.  Here every
 // wavefront runs a software pipeline of its own: the 16 (48) MFMAs of output tile u + 1 are issued between the activations of
-// tile u (one `tanh` per MFMA gap: v_exp, v_add, v_rcp, v_fma + half a v_cvt_pk = 26.5 issue cycles against the MFMA's 32 - the
-// factor 2 / ln 2 is in the packed weights, the bias is the accumulator's initial value), layer 3 rides behind (two MFMAs per
+// tile u (one activation per MFMA gap: v_exp, v_add, v_rcp (+ v_fma, float32-grade) + half a v_cvt_pk = 22.5 / 26.5 issue cycles against the
+// MFMA's 32 - the factor 2 / ln 2 is in the packed weights, the bias is the accumulator's initial value, bf16: 1 - 2 r is in the next layer's), layer 3 rides behind (two MFMAs per
 // tile) and - float32-grade - layer 2's first chain runs inside layer 1's activations.  The weights of the 256 x 256 layer travel
 // into LDS THROUGH REGISTERS (LDS-DMA needs none, but a piece costs the issuing wavefront 100 - 180 cycles, lands slowly, and every
 // other vector-memory operation of the wavefront queues behind it: EXPERIMENTS.md round 6); a workgroup keeps them for `passes`
@@ -179,42 +179,38 @@ __device__ __forceinline__ skp_bf16x8 skp_frag4(const uint32_t (&w)[4]) {
 // themselves, so an operation sits between its input's pin and its output's.  No instruction is emitted for a pin.
 #define SKP_PIN(v) asm volatile("" : "+v"(v))
 struct SkpAct {
-  float e[16], r[16];
+  float e[16];
   uint32_t w[8];
   float hprev;
 };
+// bf16 mode: what is packed is r = 1 / (2^y + 1), not tanh = 1 - 2 r - the next layer's packed weights are - 2 W and its bias
+// b + W 1 (skyjo_vec_mlp_create), so the activation is v_exp, v_add, v_rcp and half a v_cvt_pk: 22.5 issue cycles per value
+// (same-box A/B: net 30.6 -> 28.9 us).  r is what gets rounded to bf16 then: + 20 % on this mode's error against the float32 module,
+// which the weights' rounding dominates - 0.0020 mean against the tolerance of 0.01 (tests/test_gpu_policy_net.py).  The
+// float32-grade mode keeps 1 - 2 r: there the fold saves 1 % (both pipes bound it) and costs half as much again in error.
 __device__ __forceinline__ void skp_act_gap(SkpAct &a, const int i, const skp_f32x16 &acc) {
-  const bool sa = i < 16, sb = i >= 1 && i <= 16, sc = i >= 2 && i <= 17, pair = sc && ((i - 2) & 1);
-  float ein = 0.f, rin = 0.f, eo = 0.f, ro = 0.f, hv = 0.f;
+  const bool sa = i < 16, sb = i >= 1 && i <= 16, pair = sb && ((i - 1) & 1);
+  float ein = 0.f, eo = 0.f, ro = 0.f;
   uint32_t w = 0;
   if (sb) {
     ein = a.e[i - 1];
     SKP_PIN(ein);
   }
-  if (sc) {
-    rin = a.r[i - 2];
-    SKP_PIN(rin);
-  }
   if (sa) eo = __builtin_amdgcn_exp2f(acc[i]);  // (the accumulator IS (2 / ln 2) (w x + b): scaled weights, bias as its initial value)
-  if (sb) ro = __builtin_amdgcn_rcpf(ein + 1.0f);
-  if (sc) {
-    hv = __builtin_fmaf(rin, -2.0f, 1.0f);
-    if (pair) w = skp_pk(a.hprev, hv);
+  if (sb) {
+    ro = __builtin_amdgcn_rcpf(ein + 1.0f);
+    if (pair) w = skp_pk(a.hprev, ro);
   }
   if (sa) {
     SKP_PIN(eo);
     a.e[i] = eo;
   }
-  if (sb) {
-    SKP_PIN(ro);
-    a.r[i - 1] = ro;
-  }
   if (pair) {
     SKP_PIN(w);
-    a.w[(i - 2) >> 1] = w;
-  } else if (sc) {
-    SKP_PIN(hv);
-    a.hprev = hv;
+    a.w[(i - 1) >> 1] = w;
+  } else if (sb) {
+    SKP_PIN(ro);
+    a.hprev = ro;
   }
 }
 #define SKP_GAP_END __builtin_amdgcn_sched_barrier(0)
