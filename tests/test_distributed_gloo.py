@@ -66,3 +66,14 @@ def test_two_rank_shards_match_single_process():
         for k in ("steps", "episodes", "resets", "sum_len"):
             assert totals[k] == c[k], (k, totals[k], c[k])
     assert c["episodes"] > 0
+
+
+def test_the_gather_path_follows_the_groups_backend_not_its_name():
+    """which device the statistics record must live on is decided from the process group's backend string per device type
+    ("nccl" = RCCL -> device tensors, "gloo" -> host tensors, a mixed "cpu:gloo,cuda:nccl" group -> either, mpi / ucc -> either),
+    not from `backend == "gloo"`."""
+    from skyjo_rl_amd.distributed import _backend_devices
+
+    assert _backend_devices("nccl") == {"cuda"} and _backend_devices("gloo") == {"cpu"}
+    assert _backend_devices("cpu:gloo,cuda:nccl") == {"cpu", "cuda"}
+    assert _backend_devices("mpi") == {"cpu", "cuda"} and _backend_devices("ucc") == {"cpu", "cuda"}
