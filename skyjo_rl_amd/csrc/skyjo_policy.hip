@@ -102,25 +102,29 @@ __device__ __forceinline__ void skp_finish(const skp_f32x16 &acc, const int lane
     }
   }
   if (draw.enable) {
-    // a game's 32 outputs sit in two lanes (this one and lane ^ 32: rows 4h .. 4h+3 of every block of 8): swap halves
-    float full[32];
+    // a game's 32 outputs sit in two lanes (this one and lane ^ 32: rows 4h .. 4h + 3 of every block of 8) - each half works on
+    // the blocks of four actions it holds, eight values cross (sk_draw_action_pair: the same arithmetic, in the same order, as
+    // k_sample's one-lane form)
+    float v[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float other = __shfl_xor(acc[r], 32, 64);
-      const int blk8 = r >> 2, i4 = r & 3;
-      full[8 * blk8 + i4] = h ? other : acc[r];      // rows 0..3 of the block belong to the h = 0 lane
-      full[8 * blk8 + 4 + i4] = h ? acc[r] : other;  // rows 4..7 to the h = 1 lane
-    }
-    if (h == 0 && g < R.n) {
-      uint32_t mw[7];
+    for (int r = 0; r < 16; r++) v[r] = acc[r];
+    uint32_t mw4[4] = {0u, 0u, 0u, 0u};
+    if (g < R.n) {
+      // (this half's word offsets are the same in every batch: left alone the compiler computes them - as 64-bit pairs - ahead of
+      // the batch loop and spills them, and a kernel with a private segment costs ~ 1 us more per launch.  hq is opaque.)
+      int hq = h;
+      asm volatile("" : "+v"(hq));
+      const uint8_t *rec = (const uint8_t *)skp_piece(R, g, 0);
 #pragma unroll
-      for (int k = 0; k < 7; k++) {
-        const int off = draw.mask_offset + 4 * k;  // (the mask starts on a 4-byte boundary: a word never straddles two pieces)
-        mw[k] = *(const uint32_t *)((const uint8_t *)skp_piece(R, g, off >> 4) + (off & 15));
+      for (int q = 0; q < 4; q++) {
+        const int off = draw.mask_offset + 4 * min(2 * q + hq, 6);  // (the mask starts on a 4-byte boundary: a word never straddles two pieces)
+        mw4[q] = *(const uint32_t *)(rec + (R.planar ? (off >> 4) * 1024 + (off & 15) : off));
       }
-      float lp = 0.f;
-      draw.actions[g] = sk_draw_action(full, mw, draw.no_masking, draw.seed, draw.ticket, draw.game_id0 + (uint64_t)g,
-                                       draw.logp ? &lp : nullptr, nullptr);
+    }
+    float lp = 0.f;
+    const int a = sk_draw_action_pair(v, mw4, h, draw.no_masking, draw.seed, draw.ticket, draw.game_id0 + (uint64_t)g, draw.logp ? &lp : nullptr);
+    if (h == 0 && g < R.n) {
+      draw.actions[g] = a;
       if (draw.logp) draw.logp[g] = lp;
     }
   }
@@ -385,7 +389,11 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
   for (int pass = 1; pass < passes; pass++) {
     const long long batch = (long long)blockIdx.x * passes + pass;
     if (batch * SKP_GAMES_PER_WG >= R.n) break;  // (uniform: a workgroup's later batches may lie beyond the last game)
-    skp_batch_bf16<false>(net, R, out, draw, w2s, w3s, b2s, batch, pass + 1 < passes, lane, wave, col, h, ob);
+    // (everything that depends on the lane alone is the same in every batch: the compiler would compute it all ahead of the loop
+    // and, 256 registers being in use, spill it - a private segment costs the launch ~ 1 us.  The lane number is opaque in here.)
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    skp_batch_bf16<false>(net, R, out, draw, w2s, w3s, b2s, batch, pass + 1 < passes, lane_o, wave, lane_o & 31, lane_o >> 5, ob);
   }
   SKP_RSTAMP(30);
 }
@@ -398,11 +406,13 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
 // product, is left out): the logits and values agree with the float32 module to 1e-4 (tests/test_gpu_policy_net.py) at
 // three times the matrix work of the bf16 form.  The observations are int8 and exact in one bf16, so layer 1 takes two.
 //   * 48 MFMAs per output tile of layer 2 and 6 of layer 3 against 16 activations: the matrix pipe bounds this form.  A stage
-//     is 54 gaps; value v's activation is spread over gaps 3v + 2 .. 3v + 4, a pair's split into hi and lo over the three after.
-//   * The 256 x 256 layer is 256 KB (hi + lo) against 160 KB of LDS: it passes through two 64 KB buffers in quarters of two
-//     output tiles, each quarter requested by LDS-DMA two stages before its first MFMA; ONE workgroup barrier per quarter
-//     (everybody's share of the next quarter has landed, everybody is through with the buffer that is refilled next).
-//   * Layer 2's first chain (48 MFMAs) runs inside layer 1's activations, k-step by k-step as layer 1's tiles appear.
+//     is 54 gaps; value v's activation is spread over gaps 3v + 1 .. 3v + 3, a pair's split into hi and lo over the three after.
+//   * The 256 x 256 layer is 256 KB (hi + lo) against 160 KB of LDS: it passes through a ring of three 32 KB output tiles,
+//     tile U + 3 travelling - through registers, one KiB per wavefront at a time - into the slot tile U has left while stage U
+//     runs; ONE workgroup barrier per stage (everybody's share of the next tile is written, everybody is through with the slot
+//     that is refilled next).
+//   * Layer 1's weight fragments come straight from memory, progressively; its tiles' activations overlap nothing (EXPERIMENTS
+//     round 6, 10 and 18).
 // ------------------------------------------------------------------------------------------------------------------
 struct SkpActS {
   float b[16], e[16], r[16], hv[16];
@@ -484,7 +494,7 @@ __device__ __forceinline__ void skp_act_split_gap(SkpActS &a, const int g, const
     a.lo[p] = w;
   }
 }
-#define SKP_SPLIT_GAPS 54  // a stage of layers 2 / 3: G = 3, OFF = 2
+#define SKP_SPLIT_GAPS 54  // a stage of layers 2 / 3: G = 3, OFF = 1
 #define SKP_L1_GAPS 21     // a tile of layer 1: G = 1, OFF = 0
 
 // One output tile of the 256 x 256 layer in LDS: [hi, lo][16 k-steps][64 lanes] fragments = 32 KB; a ring of three of them.

@@ -172,6 +172,48 @@ def test_fused_policy_loop_plays_legal_games():
     env.close()
 
 
+@pytest.mark.parametrize("precision,N,no_masking", [("bf16", 4, False), ("fp32", 3, False), ("bf16", 2, True)])
+def test_pair_draw_equals_one_lane_draw_on_sharp_logits(precision, N, no_masking):
+    """The draw made in the net's launch (two lanes per game, csrc/skyjo_draw.h: sk_draw_action_pair) against skyjo_vec_sample_actions
+    on the logits the same launch wrote (one lane per game): same actions, same log-probabilities, bit for bit - on logits spread over
+    +- 40 (last layer times 60: most exponentials underflow to 0, the fall-back to the last possible action is taken, the CDF has
+    long flat stretches), over 20 011 games, both phases, with and without the mask.  Every drawn action is legal under the mask."""
+    import torch
+
+    from skyjo_rl_amd import SkyjoVecEnv
+    from skyjo_rl_amd.action_mask_model import ActionMaskModel, FusedNet
+
+    torch.manual_seed(5)
+    B = 20011
+    env = SkyjoVecEnv(B, num_players=N)
+    env.seed(None, 21)
+    model = ActionMaskModel(obs_dim=env.obs_dim).cuda()
+    with torch.no_grad():
+        model.policy[-1].weight.mul_(60.0)
+    pol = FusedNet(model.policy, precision=precision)
+    rec = env.reset()
+    seen = torch.zeros(26, dtype=torch.int64, device="cuda")
+    for t in range(30):
+        lg = torch.empty((B, 26), device="cuda")
+        lp_a = torch.empty(B, device="cuda")
+        a = pol.act(env, rec, seed=13, ticket=t, no_masking=no_masking, logp=lp_a, logits=lg)
+        if t == 0:
+            assert float(lg.abs().max()) > 20.0
+        lp_b = torch.empty(B, device="cuda")
+        a_ref = env.sample_actions(lg, rec, seed=13, ticket=t, no_masking=no_masking, logp=lp_b)
+        assert torch.equal(a, a_ref)
+        assert torch.equal(lp_a, lp_b)
+        mask = env.split(rec).action_mask
+        legal = mask.gather(1, a.long()[:, None]).squeeze(1).eq(1)
+        if not no_masking:
+            assert bool(legal.all())
+        seen += torch.bincount(a.long(), minlength=26)
+        # (without the mask an illegal pick is possible: play the masked draw on, so that both phases keep coming)
+        rec = env.step(a if not no_masking else env.sample_actions(lg, rec, seed=13, ticket=1000 + t))
+    assert int((seen > 0).sum()) >= 20  # draws all over the action range, both halves of the lane pair
+    env.close()
+
+
 def test_act_equals_forward_then_sample_bit_for_bit():
     import torch
 
