@@ -221,12 +221,21 @@ __device__ __forceinline__ void skp_act_gap(SkpAct &a, const int i, const skp_f3
 
 // ------------------------------------------------------------------------------------------------------------------
 // bf16 mode (SKYJO_MLP_BF16): single bf16 weights and inter-layer activations, float32 accumulation.
-// LDS: the 256 x 256 layer (128 KB), layer 3 (16 KB), layer 2's scaled bias (1 KB).
+// LDS: the 256 x 256 layer (128 KB), layer 3 (16 KB), layer 1 (16 KB) - all 160 KB; the biases come from memory.
 // ------------------------------------------------------------------------------------------------------------------
-// Stage U of layers 2 / 3: the 16 MFMAs of tile U + 1 (gaps 0 .. 15) and layer 3's two k-steps of tile U - 1 (gaps 16, 17) between
-// the activations of tile U.  a0 / a1: the weight fragments of the first two MFMAs (read two gaps ahead, like all the others).
+// Stage U of layers 2 / 3: the 16 MFMAs of tile U + 1 (gaps 0 .. 15), layer 3's two k-steps of tile U - 1 (gaps 16, 17) and the bias
+// of tile U + 2 (gap 18) between the activations of tile U.  a0 / a1: the weight fragments of the first two MFMAs (read two gaps
+// ahead, like all the others).
+// The biases are MFMAs too: a 17th k-step whose weight fragment holds (hi, lo) - the float32 bias as two bf16 - in k = 0, 1 against a
+// fragment of ones gives hi + lo in every game's column, exact to 2^-17.  That is ONE register per tile and lane, held for the whole
+// launch (bq), no LDS (the three layers fill all 160 KB) and no loads in here: a load from memory inside this pipeline costs the
+// wavefront ~ 100 cycles, four per stage made every stage a third longer (EXPERIMENTS round 6, 24).
+__device__ __forceinline__ skp_bf16x8 skp_bias_frag(const uint32_t w) {
+  const uint32_t q[4] = {w, 0u, 0u, 0u};
+  return skp_frag4(q);
+}
 template <int U>
-__device__ __forceinline__ void skp_stage_bf16(const uint4 *w2s, const uint4 *w3s, const float *b2s, const int lane, const int h,
+__device__ __forceinline__ void skp_stage_bf16(const uint4 *w2s, const uint4 *w3s, const uint32_t (&bq)[9], const skp_bf16x8 &ones, const int lane,
                                                const skp_bf16x8 (&h1)[16], skp_f32x16 &cur, skp_f32x16 &acc3, skp_bf16x8 &f0, skp_bf16x8 &f1,
                                                skp_bf16x8 &a0, skp_bf16x8 &a1, skp_f32x16 &bias_next) {
   skp_f32x16 nxt = bias_next;  // (scaled) bias of tile U + 1: the chain's initial accumulator
@@ -235,24 +244,21 @@ __device__ __forceinline__ void skp_stage_bf16(const uint4 *w2s, const uint4 *w3
   SkpAct act;
   skp_f32x16 bn;
 #pragma unroll
-  for (int i = 0; i < 18; i++) {
+  for (int i = 0; i < 19; i++) {
     // LDS reads, two gaps ahead of their MFMA: the rest of chain U + 1, layer 3's fragments, the head of chain U + 2
     if (i + 2 < 16) {
       if (U < 7) a[i + 2] = skp_frag(w2s + ((U + 1) * 16 + i + 2) * 64 + lane);
     } else if (i + 2 < 18) {
       if (U > 0) a[i + 2] = skp_frag(w3s + (2 * (U - 1) + (i + 2 - 16)) * 64 + lane);
-    } else if (U < 6) {
+    } else if (i + 2 < 20 && U < 6) {
       a[i + 2] = skp_frag(w2s + ((U + 2) * 16 + (i - 16)) * 64 + lane);
-    }
-    if (U < 6 && i >= 8 && i < 12) {  // tile U + 2's bias (every lane half reads the same 16 bytes: a broadcast)
-      const int q = i - 8;
-      const float4 b = *(const float4 *)(b2s + 32 * (U + 2) + 8 * q + 4 * h);
-      bn[4 * q] = b.x, bn[4 * q + 1] = b.y, bn[4 * q + 2] = b.z, bn[4 * q + 3] = b.w;
     }
     if (i < 16) {
       if (U < 7) nxt = SKP_MFMA(a[i], h1[i], nxt);
-    } else if (U > 0) {
-      acc3 = SKP_MFMA(a[i], i == 16 ? f0 : f1, acc3);
+    } else if (i < 18) {
+      if (U > 0) acc3 = SKP_MFMA(a[i], i == 16 ? f0 : f1, acc3);
+    } else if (U < 6) {
+      bn = SKP_MFMA(skp_bias_frag(bq[U + 2]), ones, skp_zero());
     }
     skp_act_gap(act, i, cur);
     SKP_GAP_END;
@@ -261,49 +267,42 @@ __device__ __forceinline__ void skp_stage_bf16(const uint4 *w2s, const uint4 *w3
   cur = nxt;
   if (U < 6) a0 = a[18], a1 = a[19], bias_next = bn;
 }
-__device__ __forceinline__ skp_f32x16 skp_bias_tile(const float *b2s, const int u, const int h) {
-  skp_f32x16 r;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const float4 b = *(const float4 *)(b2s + 32 * u + 8 * q + 4 * h);
-    r[4 * q] = b.x, r[4 * q + 1] = b.y, r[4 * q + 2] = b.z, r[4 * q + 3] = b.w;
-  }
-  return r;
-}
 
 // One batch of 256 games (32 per wavefront).  FIRST: the workgroup's first batch, which also brings the weights of layers 2 and 3
 // into LDS; `more`: another batch follows (its record is requested behind layer 1).
 template <bool FIRST>
 __device__ __forceinline__ void skp_batch_bf16(const SkMlpDev &net, const SkMlpRecords &R, float *const out, const SkMlpDraw &draw, uint4 *w2s,
-                                               uint4 *w3s, float *b2s, const long long batch, const bool more, const int lane, const int wave,
-                                               const int col, const int h, uint32_t (&ob)[8]) {
+                                               uint4 *w3s, uint4 *w1s, const long long batch, const bool more, const int lane, const int wave,
+                                               const int col, const int h, uint32_t (&ob)[8], uint32_t (&bq)[9]) {
   SKP_STAMP_DECL;
   const long long g = (batch * SKP_WG + wave) * 32 + col;
-  // ---- what this batch reads from memory, up front: layer 1's sixteen fragments (their 64 registers are the ones its results
-  // grow into), layer 3's bias; the record was requested before the loop / behind the previous batch's layer 1 ----
+  // ---- How a launch starts (stamped, EXPERIMENTS round 6, 24): the compute unit has ONE vector memory pipe, a 16-byte-per-lane load
+  // keeps it busy for 16 cycles, and a wavefront's loads queue in it behind everybody else's.  Eight wavefronts that each requested
+  // the record (2 loads), layer 1's sixteen fragments, layer 3's bias (4) and their 18 KiB of layers 2 / 3 at once waited 6 200
+  // cycles for layer 1's first operand.  So: all three layers' weights live in LDS (128 + 16 + 16 KB: all of it), a wavefront
+  // requests its record, its two KiB of layer 1 and nine bias values (4-byte loads), writes layer 1 to LDS - ONE workgroup barrier,
+  // 2 500 cycles after the wavefront's first instruction: kernel arguments, then one round trip to memory - and starts; its 18 KiB
+  // of layers 2 / 3 are requested three pieces per tile of layer 1 and written to LDS two tiles later (through registers: LDS-DMA
+  // needs none, but a piece costs the issuing wavefront 100 - 180 cycles and the 144 KB took ~ 20 000 cycles to land; the
+  // registers are free here, layer 1's results have not been produced yet).  The biases never touch LDS: skp_stage_bf16. ----
+  skp_u32x4 stg[18];  // (a native vector type: HIP's uint4 is a struct of unions, and an array of them stays in scratch)
+  float bf[9];
+  if (FIRST) {
+    const skp_u32x4 s0 = *(const skp_u32x4 *)(net.w1 + (2 * wave) * 64 + lane), s1 = *(const skp_u32x4 *)(net.w1 + (2 * wave + 1) * 64 + lane);
+    // this lane's biases: output row 32 u + col of layer 2 (net.b2: float32 [256], scaled), row col of layer 3 (net.b3 is laid out
+    // per lane and accumulator register: row (r & 3) + 8 (r >> 2) + 4 h' at [32 h'][r])
+#pragma unroll
+    for (int u = 0; u < 8; u++) bf[u] = net.b2[32 * u + col];
+    bf[8] = net.b3[(32 * ((col >> 2) & 1)) * 16 + (col & 3) + 4 * (col >> 3)];
+    *(skp_u32x4 *)(w1s + (2 * wave) * 64 + lane) = s0, *(skp_u32x4 *)(w1s + (2 * wave + 1) * 64 + lane) = s1;
+    SKP_STAMP(2);
+    __syncthreads();  // layer 1 is in LDS
+    SKP_STAMP(16);
+  }
   skp_bf16x8 x[2], w1f[16];
 #pragma unroll
-  for (int k = 0; k < 16; k++) w1f[k] = skp_frag(net.w1 + k * 64 + lane);
-  skp_f32x16 acc3;
-  {
-    const float4 *bp = (const float4 *)(net.b3 + (size_t)lane * 16);
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const float4 b = bp[q];
-      acc3[4 * q] = b.x, acc3[4 * q + 1] = b.y, acc3[4 * q + 2] = b.z, acc3[4 * q + 3] = b.w;
-    }
-  }
-  // In the first batch the weights of layers 2 and 3 travel behind them, 18 KB per wavefront through registers (pieces (8 j + w)
-  // of the 128 + 16 one-KiB pieces), and are written to LDS between layer 1's activations as they arrive.  (LDS-DMA needs no
-  // registers, but a piece costs the issuing wavefront 100 - 180 cycles and the 144 KB took ~ 20 000 cycles to land - stamped;
-  // the registers are free here: layer 1's results have not been produced yet.)
-  skp_u32x4 stg[18];  // (a native vector type: HIP's uint4 is a struct of unions, and an array of them stays in scratch)
-  if (FIRST) {
-    if (threadIdx.x < SKP_HIDDEN) b2s[threadIdx.x] = net.b2[threadIdx.x];
-#pragma unroll
-    for (int j = 0; j < 18; j++)
-      stg[j] = *(const skp_u32x4 *)(j < 16 ? net.w2 + (j * 8 + wave) * 64 + lane : net.w3 + ((j - 16) * 8 + wave) * 64 + lane);
-  }
+  for (int k = 0; k < 16; k++) w1f[k] = skp_frag(w1s + k * 64 + lane);
+  skp_f32x16 acc3, cur, bias_next;
   skp_inputs(R, ob, h, x);
   SKP_STAMP(1 + 14 * (FIRST ? 0 : 1));
   // ---- layer 1: 31 (+1) -> 256, tanh (the bias rides in the product: feature 31 is 1); the result tiles become the 16
@@ -321,10 +320,16 @@ __device__ __forceinline__ void skp_batch_bf16(const SkMlpDev &net, const SkMlpR
       for (int i = 0; i < 18; i++) {
         if (t < 7 && i == 0) nxt = SKP_MFMA(w1f[2 * t + 2], x[0], skp_zero());
         if (t < 7 && i == 1) nxt = SKP_MFMA(w1f[2 * t + 3], x[1], nxt);
-        if (FIRST && (i == 5 || i == 11)) {
-          const int j = 2 * t + (i == 11);
-          *(skp_u32x4 *)(w2s + (j * 8 + wave) * 64 + lane) = stg[j];
-          if (t == 7) *(skp_u32x4 *)(w3s + ((i == 11) * 8 + wave) * 64 + lane) = stg[16 + (i == 11)];
+        // the wavefront's 18 KiB of layers 2 / 3: piece j requested in tile j / 3, written to LDS two tiles on.  (All eighteen requested
+        // up front - eight wavefronts at once, right behind their barrier - kept every wavefront 2 500 cycles in the queue of the pipe.)
+        if (FIRST && t < 6 && (i == 2 || i == 7 || i == 12)) {
+          const int j = 3 * t + (i == 7) + 2 * (i == 12);
+          stg[j] = *(const skp_u32x4 *)(j < 16 ? net.w2 + (j * 8 + wave) * 64 + lane : net.w3 + ((j - 16) * 8 + wave) * 64 + lane);
+        }
+        if (FIRST && t >= 2 && (i == 4 || i == 9 || i == 14)) {
+          const int j = 3 * (t - 2) + (i == 9) + 2 * (i == 14);
+          if (j < 16) *(skp_u32x4 *)(w2s + (j * 8 + wave) * 64 + lane) = stg[j];
+          else *(skp_u32x4 *)(w3s + ((j - 16) * 8 + wave) * 64 + lane) = stg[j];
         }
         skp_act_gap(act, i, acc);
         SKP_GAP_END;
@@ -334,32 +339,43 @@ __device__ __forceinline__ void skp_batch_bf16(const SkMlpDev &net, const SkMlpR
     }
   }
   SKP_STAMP(3 + 14 * (FIRST ? 0 : 1));
+  if (FIRST) {  // (before the next record is requested: the waits count in order, and behind a branch the compiler waits for everything)
+#pragma unroll
+    for (int u = 0; u < 9; u++) {
+      const uint32_t hi = skp_pk(bf[u], 0.f);
+      bq[u] = h ? 0u : skp_pk(bf[u], bf[u] - __uint_as_float(hi << 16));
+    }
+  }
   if (FIRST) __syncthreads();  // everybody's share of the weights is in LDS
   // the next batch's record, requested now: it arrives while layers 2 and 3 run
   if (more) skp_record_load(R, ((batch + 1) * SKP_WG + wave) * 32 + col, ob);
   SKP_STAMP(4 + 14 * (FIRST ? 0 : 1));
   // ---- layers 2 and 3 ----
-  skp_f32x16 cur = skp_bias_tile(b2s, 0, h), bias_next = skp_bias_tile(b2s, 1, h);
+  const uint32_t oq[4] = {h ? 0u : 0x3f803f80u, 0u, 0u, 0u};  // ones in k = 0, 1
+  const skp_bf16x8 ones = skp_frag4(oq);
+  cur = SKP_MFMA(skp_bias_frag(bq[0]), ones, skp_zero());
+  acc3 = SKP_MFMA(skp_bias_frag(bq[8]), ones, skp_zero());
+  bias_next = SKP_MFMA(skp_bias_frag(bq[1]), ones, skp_zero());
 #pragma unroll
   for (int ks = 0; ks < 16; ks++) cur = SKP_MFMA(skp_frag(w2s + ks * 64 + lane), h1[ks], cur);
   skp_bf16x8 f0, f1, a0 = skp_frag(w2s + 16 * 64 + lane), a1 = skp_frag(w2s + 17 * 64 + lane);
   SKP_GAP_END;
   SKP_STAMP(5 + 14 * (FIRST ? 0 : 1));
-  skp_stage_bf16<0>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  skp_stage_bf16<0>(w2s, w3s, bq, ones, lane, h1, cur, acc3, f0, f1, a0, a1, bias_next);
   SKP_STAMP(6 + 14 * (FIRST ? 0 : 1));
-  skp_stage_bf16<1>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  skp_stage_bf16<1>(w2s, w3s, bq, ones, lane, h1, cur, acc3, f0, f1, a0, a1, bias_next);
   SKP_STAMP(7 + 14 * (FIRST ? 0 : 1));
-  skp_stage_bf16<2>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  skp_stage_bf16<2>(w2s, w3s, bq, ones, lane, h1, cur, acc3, f0, f1, a0, a1, bias_next);
   SKP_STAMP(8 + 14 * (FIRST ? 0 : 1));
-  skp_stage_bf16<3>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  skp_stage_bf16<3>(w2s, w3s, bq, ones, lane, h1, cur, acc3, f0, f1, a0, a1, bias_next);
   SKP_STAMP(9 + 14 * (FIRST ? 0 : 1));
-  skp_stage_bf16<4>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  skp_stage_bf16<4>(w2s, w3s, bq, ones, lane, h1, cur, acc3, f0, f1, a0, a1, bias_next);
   SKP_STAMP(10 + 14 * (FIRST ? 0 : 1));
-  skp_stage_bf16<5>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  skp_stage_bf16<5>(w2s, w3s, bq, ones, lane, h1, cur, acc3, f0, f1, a0, a1, bias_next);
   SKP_STAMP(11 + 14 * (FIRST ? 0 : 1));
-  skp_stage_bf16<6>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  skp_stage_bf16<6>(w2s, w3s, bq, ones, lane, h1, cur, acc3, f0, f1, a0, a1, bias_next);
   SKP_STAMP(12 + 14 * (FIRST ? 0 : 1));
-  skp_stage_bf16<7>(w2s, w3s, b2s, lane, h, h1, cur, acc3, f0, f1, a0, a1, bias_next);
+  skp_stage_bf16<7>(w2s, w3s, bq, ones, lane, h1, cur, acc3, f0, f1, a0, a1, bias_next);
   acc3 = SKP_MFMA(skp_frag(w3s + 14 * 64 + lane), f0, acc3);
   acc3 = SKP_MFMA(skp_frag(w3s + 15 * 64 + lane), f1, acc3);
   SKP_STAMP(13 + 14 * (FIRST ? 0 : 1));
@@ -368,9 +384,9 @@ __device__ __forceinline__ void skp_batch_bf16(const SkMlpDev &net, const SkMlpR
 }
 
 __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_bf16(const SkMlpArgs A) {
-  __shared__ uint4 w2s[8 * 16 * 64];
-  __shared__ uint4 w3s[16 * 64];
-  __shared__ float b2s[SKP_HIDDEN];
+  __shared__ uint4 w2s[8 * 16 * 64];  // the 256 x 256 layer (128 KB)
+  __shared__ uint4 w3s[16 * 64];      // layer 3 (16 KB)
+  __shared__ uint4 w1s[16 * 64];      // layer 1 (16 KB): 160 KB, all of the compute unit's LDS
   // (the branch's descriptor is read from the kernel-argument segment by index: one set of scalar registers, not two and a select)
   const SkMlpDev &net = A.net[blockIdx.y];
   float *const out = A.out[blockIdx.y];
@@ -384,7 +400,8 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
   SKP_RSTAMP(29);
   uint32_t ob[8];
   skp_record_load(R, ((long long)blockIdx.x * passes * SKP_WG + wave) * 32 + col, ob);
-  skp_batch_bf16<true>(net, R, out, draw, w2s, w3s, b2s, (long long)blockIdx.x * passes, passes > 1, lane, wave, col, h, ob);
+  uint32_t bq[9];
+  skp_batch_bf16<true>(net, R, out, draw, w2s, w3s, w1s, (long long)blockIdx.x * passes, passes > 1, lane, wave, col, h, ob, bq);
 #pragma unroll 1
   for (int pass = 1; pass < passes; pass++) {
     const long long batch = (long long)blockIdx.x * passes + pass;
@@ -393,7 +410,7 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
     // and, 256 registers being in use, spill it - a private segment costs the launch ~ 1 us.  The lane number is opaque in here.)
     int lane_o = lane;
     asm volatile("" : "+v"(lane_o));
-    skp_batch_bf16<false>(net, R, out, draw, w2s, w3s, b2s, batch, pass + 1 < passes, lane_o, wave, lane_o & 31, lane_o >> 5, ob);
+    skp_batch_bf16<false>(net, R, out, draw, w2s, w3s, w1s, batch, pass + 1 < passes, lane_o, wave, lane_o & 31, lane_o >> 5, ob, bq);
   }
   SKP_RSTAMP(30);
 }

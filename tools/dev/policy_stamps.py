@@ -31,6 +31,10 @@ def seg(a, b, label):
     d = st[:, b] - st[:, a]
     rows.append((label, float(np.median(d)), float(d.min()), float(d.max())))
 seg(0, 1, "pass0 record waited, loads issued (fp32: + first two tiles staged)")
+if prec == "bf16":
+    seg(0, 2, "  pass0: own two KiB of layer 1 arrived and written")
+    seg(2, 16, "  pass0: barrier (layer 1 in LDS)")
+    seg(16, 1, "  pass0: loads issued, fragments read, record unpacked")
 seg(1, 3, "pass0 layer 1 (+ staging writes)")
 if prec == "bf16":
     seg(3, 4, "pass0 barrier (weights in LDS)")
