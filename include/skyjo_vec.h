@@ -321,7 +321,7 @@ int skyjo_vec_get_option(const skyjo_vec *h, int option, int64_t *value_out);
  *   uniform_out float32 [n] (the uniforms in [0, 1), for tests) or NULL.
  * Arithmetic is float32: probabilities agree with torch.softmax to 1e-6 (tests/test_gpu_sampler.py).  The order of the sums is part
  * of the definition (csrc/skyjo_draw.h: exponentials in blocks of four actions, block totals left to right, the CDF of a block
- * starting from the total before it; the action is the smallest k whose CDF value exceeds uniform * sum), so that the draw made in
+ * starting from the total before it; the action is the smallest k of non-zero probability whose CDF value exceeds uniform * sum), so that the draw made in
  * the net's own launch (skyjo_vec_mlp_act_value: two lanes per game) and this one (one lane per game) give the same bits. */
 int skyjo_vec_sample_actions(skyjo_vec *h, const void *records, const float *logits, int64_t n, uint64_t seed,
                              uint64_t ticket, int32_t no_masking, int32_t *actions_out, float *logp_out,

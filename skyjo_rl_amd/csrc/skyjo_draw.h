@@ -28,7 +28,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // order of the float32 sums is part of the definition, so that "net + draw in one launch" and "net, then k_sample" give the same
 // bits: the exponentials are summed in BLOCKS of four actions (block j = actions 4j .. 4j + 3, left to right; block 6 = actions
 // 24, 25), the block totals left to right (P[j + 1] = P[j] + B[j], sum = P[7]), and the CDF inside block j starts from P[j].  The
-// action is the smallest k whose CDF value exceeds u * sum.
+// action is the smallest k WITH A NON-ZERO PROBABILITY whose CDF value exceeds u * sum.  (A block's CDF starts from a total that was
+// rounded on another path than the running sum of the block before: it can lie one ulp above it, and without the condition a masked
+// action at the head of a block was drawn once in ~ 10^7 draws - tests/test_gpu_sampler.py draws 2 x 10^8.)
 #define SK_DRAW_FLOAT_MIN (-3.4028234663852886e38f)  // torch.finfo(float32).min == ray's FLOAT_MIN
 __device__ __forceinline__ float sk_draw_uniform(uint64_t seed, uint64_t ticket, uint64_t gid) {
   uint32_t u0, u1, u2, u3;
@@ -73,7 +75,7 @@ __device__ __forceinline__ int sk_draw_action(const float *row, const uint32_t *
       if (k < SKYJO_NUM_ACTIONS) {
         acc += e[k];
         last_on = e[k] > 0.f ? k : last_on;
-        a = (a < 0 && acc > target) ? k : a;
+        a = (a < 0 && e[k] > 0.f && acc > target) ? k : a;
       }
     }
   }
@@ -132,7 +134,7 @@ __device__ __forceinline__ int sk_draw_action_pair(const float (&v)[16], const u
       const bool mine = q < 3 || hh == 0;
       acc += e[4 * q + i];
       last_on = (mine && e[4 * q + i] > 0.f) ? k : last_on;
-      a = (a == 99 && mine && acc > target) ? k : a;
+      a = (a == 99 && mine && e[4 * q + i] > 0.f && acc > target) ? k : a;
     }
   }
   a = min(a, __shfl_xor(a, 32, 64));  // the smallest k of either half (a half's own candidates are in increasing k)

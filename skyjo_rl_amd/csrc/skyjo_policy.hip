@@ -422,44 +422,31 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
 // product is three MFMAs into the same float32 accumulator, w_hi h_lo + w_lo h_hi + w_hi h_hi (w_lo h_lo, 2^-16 of the
 // product, is left out): the logits and values agree with the float32 module to 1e-4 (tests/test_gpu_policy_net.py) at
 // three times the matrix work of the bf16 form.  The observations are int8 and exact in one bf16, so layer 1 takes two.
-//   * 48 MFMAs per output tile of layer 2 and 6 of layer 3 against 16 activations: the matrix pipe bounds this form.  A stage
-//     is 54 gaps; value v's activation is spread over gaps 3v + 1 .. 3v + 3, a pair's split into hi and lo over the three after.
+//   * 48 (+ 1: the bias, skp_bias_split) MFMAs per output tile of layer 2 and 6 of layer 3 against 16 activations: the matrix pipe
+//     bounds this form.  A stage is 55 gaps; value v's activation is spread over gaps 3v + 1 .. 3v + 3, a pair's split into hi and
+//     lo over the three after.
 //   * The 256 x 256 layer is 256 KB (hi + lo) against 160 KB of LDS: it passes through a ring of three 32 KB output tiles,
 //     tile U + 3 travelling - through registers, one KiB per wavefront at a time - into the slot tile U has left while stage U
 //     runs; ONE workgroup barrier per stage (everybody's share of the next tile is written, everybody is through with the slot
 //     that is refilled next).
-//   * Layer 1's weight fragments come straight from memory, progressively; its tiles' activations overlap nothing (EXPERIMENTS
-//     round 6, 10 and 18).
+//   * Layers 1 and 3 stay in LDS for the whole launch (32 KB each, hi + lo): with the ring that is all 160 KB.  Layer 1's tiles'
+//     activations overlap nothing (EXPERIMENTS round 6, 10 and 18).
 // ------------------------------------------------------------------------------------------------------------------
 struct SkpActS {
-  float b[16], e[16], r[16], hv[16];
+  float e[16], r[16], hv[16];
   uint32_t hi[8], lo[8];
   float da[8], db[8];
 };
-// The operations of gap g when value v's activation starts in gap G v + OFF (phases in consecutive gaps: multiply-add + v_exp, + 1
-// + v_rcp, 1 - 2 r) and the split of pair p = (2p, 2p + 1) into hi and lo follows in the three gaps after its second value; the
-// bias of value v is read (ds_read_b32: two addresses per wavefront, a broadcast) two gaps before it is used; b2row is the tile's
-// row of this lane's half (b2s + 32 u + 4 h) as ONE opaque register + constant offsets (left to itself the compiler computed all
-// 128 addresses ahead of the loop and spilled them).
-template <bool BIAS, int G, int OFF>
-__device__ __forceinline__ void skp_act_split_gap(SkpActS &a, const int g, const skp_f32x16 &acc, skp_lds_f32 b2row, const int h) {
+// The operations of gap g when value v's activation starts in gap G v + OFF (phases in consecutive gaps: v_exp, + 1 + v_rcp,
+// 1 - 2 r) and the split of pair p = (2p, 2p + 1) into hi and lo follows in the three gaps after its second value.  (The bias is in
+// the accumulator already: layer 1's rides in the product, layer 2's is a 17th k-step - skp_bias_split.)
+template <int G, int OFF>
+__device__ __forceinline__ void skp_act_split_gap(SkpActS &a, const int g, const skp_f32x16 &acc) {
   // (no loops over v or p here: g is a constant once the caller's gap loop is unrolled, and so is everything derived from it)
-  const int tbias = g + 2 - OFF, ta = g - OFF, tb = ta - 1, tc = ta - 2;
-  if (BIAS && tbias >= 0 && tbias % G == 0 && tbias / G < 16) {
-    const int v = tbias / G;
-    a.b[v] = b2row[(v & 3) + 8 * (v >> 2)];
-  }
-  if (BIAS && OFF < 2 && g == 0) a.b[0] = b2row[0];  // (value 0 starts before gap 2: its bias is read in the first gap)
+  const int ta = g - OFF, tb = ta - 1, tc = ta - 2;
   if (ta >= 0 && ta % G == 0 && ta / G < 16) {
     const int v = ta / G;
-    float eo;
-    if (BIAS) {
-      float b = a.b[v];
-      SKP_PIN(b);
-      eo = __builtin_amdgcn_exp2f(acc[v] + b);
-    } else {
-      eo = __builtin_amdgcn_exp2f(acc[v]);
-    }
+    float eo = __builtin_amdgcn_exp2f(acc[v]);
     SKP_PIN(eo);
     a.e[v] = eo;
   }
@@ -511,7 +498,7 @@ __device__ __forceinline__ void skp_act_split_gap(SkpActS &a, const int g, const
     a.lo[p] = w;
   }
 }
-#define SKP_SPLIT_GAPS 54  // a stage of layers 2 / 3: G = 3, OFF = 1
+#define SKP_SPLIT_GAPS 55  // a stage of layers 2 / 3: G = 3, OFF = 1; the last gap holds the bias MFMA alone
 #define SKP_L1_GAPS 21     // a tile of layer 1: G = 1, OFF = 0
 
 // One output tile of the 256 x 256 layer in LDS: [hi, lo][16 k-steps][64 lanes] fragments = 32 KB; a ring of three of them.
@@ -530,15 +517,27 @@ __device__ __forceinline__ void skp_stage_store(uint4 *slot_lane, const int wave
   *(skp_u32x4 *)(slot_lane + wave * 256 + half * 128 + k * 64) = st.r[k];
 }
 
-// Stage U (54 gaps): the 48 MFMAs of tile U + 1 in gaps 0 .. 47 (k-step g / 3), the activations of tile U beside them (value v in
+// Stage U (55 gaps): the 48 MFMAs of tile U + 1 in gaps 0 .. 47 (k-step g / 3), the activations of tile U beside them (value v in
 // gaps 3 v + 1 .., the last pair's low halves in gap 51), layer 3's six MFMAs of the same tile U in gaps 48 .. 53 - its fragments
-// never outlive the stage -; on the side, tile U + 3 (the next batch's tiles 0, 1 from U = 5 on) travels into the ring slot that
+// never outlive the stage -, tile U + 1's bias in gap 54; on the side, tile U + 3 (the next batch's tiles 0, 1 from U = 5 on) travels into the ring slot that
 // tile U has just left, one KiB at a time.  The weight fragments (hi, lo) of a k-step are read three gaps ahead of its first
 // MFMA (k-step 0's by the stage before: ah / al), layer 3's (from LDS) in gaps 45 and 48.
+// This kernel has no registers to spare: the eight bias pairs of a row (one per output tile of layer 2) are spread over the TWO lanes
+// that share the row - lane l < 32 keeps tiles 0 .. 3 (k = 0, 1 of the extra k-step), lane l + 32 tiles 4 .. 7 (k = 8, 9) - four
+// registers; bq[4]: layer 3's pair (lower half).  The fragment of ones has its ones where the tile's pair is.
+__device__ __forceinline__ skp_f32x16 skp_bias_split(const uint32_t (&bq)[5], const int u, const int h, const skp_f32x16 &acc) {
+  // (built where they are used: the value is opaque, or the compiler keeps all nine fragment pairs - 72 registers - from before the batch
+  // loop on and spills them)
+  uint32_t w = bq[u == 8 ? 4 : (u & 3)];
+  asm volatile("" : "+v"(w));
+  const bool mine = u == 8 ? h == 0 : h == (u >> 2);
+  const uint32_t a[4] = {mine ? w : 0u, 0u, 0u, 0u}, b[4] = {mine ? 0x3f803f80u : 0u, 0u, 0u, 0u};
+  return SKP_MFMA(skp_frag4(a), skp_frag4(b), acc);
+}
 template <int U>
-__device__ __forceinline__ void skp_stage_split(const SkMlpDev &net, uint4 *const (&rot)[3], const uint4 *w3s, const float *b2s, const int lane,
+__device__ __forceinline__ void skp_stage_split(const SkMlpDev &net, uint4 *const (&rot)[3], const uint4 *w3s, const int lane,
                                                 const int wave, const int h, const skp_bf16x8 (&h1h)[16], const skp_bf16x8 (&h1l)[16],
-                                                skp_f32x16 &cur, skp_f32x16 &acc3, skp_bf16x8 &ah, skp_bf16x8 &al, skp_lds_f32 bias_h) {
+                                                skp_f32x16 &cur, skp_f32x16 &acc3, skp_bf16x8 &ah, skp_bf16x8 &al, const uint32_t (&bq)[5]) {
   const uint4 *wt = rot[(U + 1) % 3];  // tile U + 1 (this lane's fragment of k-step 0, hi)
   const uint4 *wn = rot[(U + 2) % 3];  // tile U + 2 (its k-step 0 is read on the way out)
   uint4 *const wr = rot[U % 3];        // tile U's slot: free since the barrier before this stage
@@ -563,6 +562,8 @@ __device__ __forceinline__ void skp_stage_split(const SkMlpDev &net, uint4 *cons
         nxt = SKP_MFMA(part == 1 ? al : ah, part == 0 ? h1l[ks] : h1h[ks], nxt);
         if (part == 2 && ks < 15) ah = nh, al = nl;
       }
+    } else if (g == 54) {  // tile U + 1's bias: the float32 value as a bf16 pair in a 17th k-step, against ones (skp_stage_bf16, skp_bias_split)
+      if (U < 7) nxt = skp_bias_split(bq, U + 1, h, nxt);
     } else {
       // layer 3, k-steps 2 U (gaps 48 .. 50) and 2 U + 1 (gaps 51 .. 53: its low halves come last, they are ready in gap 51)
       const int s2 = (g - 48) / 3, k = (g - 48) % 3;
@@ -570,7 +571,7 @@ __device__ __forceinline__ void skp_stage_split(const SkMlpDev &net, uint4 *cons
       acc3 = SKP_MFMA(s2 ? (k == 1 ? nl : nh) : (k == 1 ? w3l : w3h), k == 2 ? flo : fhi, acc3);
     }
     if (U < 6 && g == 51) w3h = skp_frag(wn), w3l = skp_frag(wn + 1024);  // (tile U + 2's first pair, into the registers layer 3's first k-step has left)
-    skp_act_split_gap<true, 3, 1>(act, g, cur, bias_h + 32 * U, h);
+    skp_act_split_gap<3, 1>(act, g, cur);
     SKP_GAP_END;
   }
   cur = nxt;
@@ -580,7 +581,7 @@ __device__ __forceinline__ void skp_stage_split(const SkMlpDev &net, uint4 *cons
 __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_net_split(const SkMlpArgs A) {
   __shared__ uint4 ring[3 * SKP_TILE_U4];  // three output tiles of the 256 x 256 layer (96 KB)
   __shared__ uint4 w3s[2 * 16 * 64];       // layer 3, [hi, lo][16 k-steps][64 lanes] (32 KB)
-  __shared__ float b2s[SKP_HIDDEN];
+  __shared__ uint4 w1s[2 * 16 * 64];       // layer 1, [hi, lo][8 tiles][2 k-steps][64 lanes] (32 KB): 160 KB, all of the CU's LDS
   // (the branch's descriptor is read from the kernel-argument segment by index: one set of scalar registers, not two and a select)
   const SkMlpDev &net = A.net[blockIdx.y];
   float *const out = A.out[blockIdx.y];
@@ -594,9 +595,18 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
   SKP_RSTAMP(29);
   uint32_t ob[8];
   skp_record_load(R, ((long long)blockIdx.x * passes * SKP_WG + wave) * 32 + col, ob);
+  float bf[5];
   {
-    // what stays in LDS for the whole launch (layer 3, layer 2's bias) and the first two tiles of the ring
-    if (threadIdx.x < SKP_HIDDEN) b2s[threadIdx.x] = net.b2[threadIdx.x];
+    // what stays in LDS for the whole launch (layers 1 and 3) and the first two tiles of the ring; the biases of layers 2 / 3 stay in
+    // registers (bq) and enter as MFMAs - no LDS left for them, and no load inside the pipeline (EXPERIMENTS round 6, 24)
+    skp_u32x4 t1[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) t1[j] = *(const skp_u32x4 *)(((wave >> 2) ? net.w1l : net.w1) + (wave & 3) * 256 + j * 64 + lane);
+#pragma unroll
+    for (int j = 0; j < 4; j++) bf[j] = net.b2[32 * (j + 4 * h) + col];
+    bf[4] = net.b3[(32 * ((col >> 2) & 1)) * 16 + (col & 3) + 4 * (col >> 3)];
+#pragma unroll
+    for (int j = 0; j < 4; j++) *(skp_u32x4 *)(w1s + wave * 256 + j * 64 + lane) = t1[j];
     skp_u32x4 t3[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) t3[j] = *(const skp_u32x4 *)(((wave >> 2) ? net.w3l : net.w3) + (wave & 3) * 256 + j * 64 + lane);
@@ -612,6 +622,11 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
     }
   }
   __syncthreads();
+  // this lane's bias values as bf16 pairs (hi, lo: exact to 2^-17): skp_bias_split
+  uint32_t bq[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) bq[j] = skp_pk(bf[j], bf[j] - __uint_as_float(skp_pk(bf[j], 0.f) << 16));
+  bq[4] = h ? 0u : bq[4];
 #pragma unroll 1
   for (int pass = 0; pass < passes; pass++) {
     const long long batch = (long long)blockIdx.x * passes + pass;
@@ -627,9 +642,9 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
     // k-steps between the activations of tile t.  Tile 2 travels into the ring on the side ----
     skp_bf16x8 x[2], w1f[4], w1n[4];  // [k-step][lo, hi] of the tile whose MFMAs come next / the one after
 #pragma unroll
-    for (int k = 0; k < 4; k++) w1f[k] = skp_frag(((k & 1) ? net.w1 : net.w1l) + (k >> 1) * 64 + lane);
+    for (int k = 0; k < 4; k++) w1f[k] = skp_frag(w1s + ((k & 1) ? 0 : 1024) + (k >> 1) * 64 + lane);
 #pragma unroll
-    for (int k = 0; k < 4; k++) w1n[k] = skp_frag(((k & 1) ? net.w1 : net.w1l) + (2 + (k >> 1)) * 64 + lane);
+    for (int k = 0; k < 4; k++) w1n[k] = skp_frag(w1s + ((k & 1) ? 0 : 1024) + (2 + (k >> 1)) * 64 + lane);
     skp_inputs(R, ob, h, x);
     SKP_STAMP(1 + 14 * (pass > 0));
     skp_bf16x8 h1h[16], h1l[16];
@@ -650,7 +665,7 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
         for (int gp = 0; gp < SKP_L1_GAPS; gp++) {
           if (t < 7 && gp < 4) nxt = SKP_MFMA(w1n[gp], x[gp >> 1], nxt);
           if (t < 6 && gp >= 4 && gp < 8)
-            w1n[gp - 4] = skp_frag((((gp - 4) & 1) ? net.w1 : net.w1l) + ((t + 2) * 2 + ((gp - 4) >> 1)) * 64 + lane);
+            w1n[gp - 4] = skp_frag(w1s + (((gp - 4) & 1) ? 0 : 1024) + ((t + 2) * 2 + ((gp - 4) >> 1)) * 64 + lane);
           if (t >= 1) {
             if (gp == 2) c0h = skp_frag(rot[0] + ks0 * 64), c0l = skp_frag(rot[0] + 1024 + ks0 * 64);
             if (gp == 8) c1h = skp_frag(rot[0] + ks1 * 64), c1l = skp_frag(rot[0] + 1024 + ks1 * 64);
@@ -660,7 +675,7 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
           // tile 2's two halves: requested in tiles 0 / 4 of layer 1, written in tiles 3 / 7
           if ((t == 0 || t == 4) && gp == 10) skp_stage_load(net, 2, wave, lane, t == 4, st);
           if ((t == 3 || t == 7) && (gp == 16 || gp == 17)) skp_stage_store(rot[2], wave, t == 7, gp - 16, st);
-          skp_act_split_gap<false, 1, 0>(act, gp, acc, (skp_lds_f32)0, h);
+          skp_act_split_gap<1, 0>(act, gp, acc);
           SKP_GAP_END;
         }
         h1h[2 * t] = skp_frag4((const uint32_t(&)[4])act.hi[0]), h1h[2 * t + 1] = skp_frag4((const uint32_t(&)[4])act.hi[4]);
@@ -674,49 +689,39 @@ __global__ __launch_bounds__(64 * SKP_WG) __attribute__((amdgpu_waves_per_eu(2, 
         cur = SKP_MFMA(cl, h1h[ks], cur);
         cur = SKP_MFMA(ch, h1h[ks], cur);
       }
+      cur = skp_bias_split(bq, 0, h, cur);
     }
     SKP_STAMP(3 + 14 * (pass > 0));
     // ---- layers 2 and 3.  One barrier per stage: everybody's share of the tile that is read two stages on has been written, and
     // everybody is through with the slot that the next stage refills ----
-    skp_f32x16 acc3;
-    {
-      const float4 *bp = (const float4 *)(net.b3 + (size_t)lane * 16);
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const float4 b = bp[q];
-        acc3[4 * q] = b.x, acc3[4 * q + 1] = b.y, acc3[4 * q + 2] = b.z, acc3[4 * q + 3] = b.w;
-      }
-    }
+    skp_f32x16 acc3 = skp_bias_split(bq, 8, h, skp_zero());
     SKP_GAP_END;
     __syncthreads();
     skp_bf16x8 ah = skp_frag(rot[1]), al = skp_frag(rot[1] + 1024);
-    uint32_t bias_off = SKP_LDS32(b2s) + 16 * h;  // (pinned as an LDS offset: through a generic pointer the reads became flat loads,
-    SKP_PIN(bias_off);                             // each waiting for every vector-memory operation in flight)
-    skp_lds_f32 bias_h = (skp_lds_f32)(uintptr_t)bias_off;
     SKP_STAMP(5 + 14 * (pass > 0));
-    skp_stage_split<0>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
+    skp_stage_split<0>(net, rot, w3s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bq);
     __syncthreads();
     SKP_STAMP(6 + 14 * (pass > 0));
-    skp_stage_split<1>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
+    skp_stage_split<1>(net, rot, w3s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bq);
     __syncthreads();
     SKP_STAMP(7 + 14 * (pass > 0));
-    skp_stage_split<2>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
+    skp_stage_split<2>(net, rot, w3s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bq);
     __syncthreads();
     SKP_STAMP(8 + 14 * (pass > 0));
-    skp_stage_split<3>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
+    skp_stage_split<3>(net, rot, w3s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bq);
     __syncthreads();
     SKP_STAMP(9 + 14 * (pass > 0));
-    skp_stage_split<4>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
+    skp_stage_split<4>(net, rot, w3s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bq);
     __syncthreads();
     SKP_STAMP(10 + 14 * (pass > 0));
-    skp_stage_split<5>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
+    skp_stage_split<5>(net, rot, w3s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bq);
     __syncthreads();
     SKP_STAMP(11 + 14 * (pass > 0));
-    skp_stage_split<6>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
+    skp_stage_split<6>(net, rot, w3s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bq);
     __syncthreads();
     if (more) skp_record_load(R, ((batch + 1) * SKP_WG + wave) * 32 + col, ob);
     SKP_STAMP(12 + 14 * (pass > 0));
-    skp_stage_split<7>(net, rot, w3s, b2s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bias_h);
+    skp_stage_split<7>(net, rot, w3s, lane, wave, h, h1h, h1l, cur, acc3, ah, al, bq);
     SKP_STAMP(13 + 14 * (pass > 0));
     skp_finish(acc3, lane, g, R, net.out_dim, out, draw);
     SKP_STAMP(14 + 14 * (pass > 0));

@@ -70,6 +70,49 @@ def test_fused_sampler_distribution_and_no_masking():
     env.close()
 
 
+def test_a_masked_action_is_never_drawn_in_two_hundred_million_draws():
+    """The draw sums its exponentials in blocks of four (csrc/skyjo_draw.h) and a block's CDF starts from a total that was rounded on
+    another path than the running sum of the block before - one ulp apart now and then.  Without the "non-zero probability"
+    condition a masked action at the head of a block was drawn about once in 10^7 draws (found by the every-record test of config
+    5).  65 536 games in the place phase (hidden cards revealed as the games go on: masked actions in every block), fixed logits, 3 000
+    tickets: 2 x 10^8 draws, none of them masked out."""
+    import torch
+
+    from skyjo_rl_amd import SkyjoVecEnv
+
+    B = 65536
+    env = SkyjoVecEnv(B, num_players=4)
+    env.seed(None, 17)
+    rec = env.reset()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    logits = (torch.randn((B, 26), generator=g, device="cuda") * 2.0).contiguous()
+    for t in range(24):  # a few rounds in, so that the masks differ from game to game
+        rec = env.step(env.sample_actions(logits, rec, seed=2, ticket=t))
+    rec = env.step(torch.full((B,), 24, dtype=torch.int32, device="cuda"))  # (those in the draw phase draw: place phase next)
+    mask = env.split(rec).action_mask
+    assert int((mask.sum(1) > 2).sum()) > B // 2  # mostly place-phase masks
+    act = torch.empty(B, dtype=torch.int32, device="cuda")
+    bad = torch.zeros((), dtype=torch.int64, device="cuda")
+    for ticket in range(3000):
+        env.sample_actions(logits, rec, seed=5, ticket=ticket, actions=act)
+        bad += (mask.gather(1, act.long()[:, None]).squeeze(1) == 0).sum()
+    assert int(bad) == 0
+    # the two-lane form of the same draw, in the policy net's own launch (65 million more)
+    from skyjo_rl_amd.action_mask_model import ActionMaskModel, FusedNet
+
+    torch.manual_seed(4)
+    model = ActionMaskModel(obs_dim=env.obs_dim).cuda()
+    with torch.no_grad():
+        model.policy[-1].weight.mul_(20.0)
+    pol = FusedNet(model.policy, precision="bf16")
+    for ticket in range(1000):
+        pol.act(env, rec, seed=6, ticket=ticket, actions=act)
+        bad += (mask.gather(1, act.long()[:, None]).squeeze(1) == 0).sum()
+    assert int(bad) == 0
+    pol.close()
+    env.close()
+
+
 def test_model_loop_with_fused_sampler():
     import torch
 
