@@ -199,7 +199,7 @@ def test_config5_env_side_every_record(precision):
     from skyjo_rl_amd.action_mask_model import ActionMaskModel, FusedNet
 
     torch.manual_seed(3)
-    B, N, T = 65536, 4, 170
+    B, N, T = 65536, 4, int(os.environ.get("SKYJO_TEST_CFG5_T", "170"))  # (a longer soak by hand: SKYJO_TEST_CFG5_T=1000)
     cfg = _cfg(N, True, 0)
     env = SkyjoVecEnv(B, **cfg)
     ora = so.OracleVec(num_envs=B, **cfg)
