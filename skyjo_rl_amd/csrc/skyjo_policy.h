@@ -27,8 +27,9 @@ struct SkMlpDev {
   const uint4 *w1;   // [8 m-tiles][2 k-steps][64 lanes] fragments, natural k order (k = feature; k = 31 carries the bias)
   const uint4 *w2;   // [8][16][64] fragments, accumulator k order
   const uint4 *w3;   // [1][16][64]
-  const float *b2;   // [256] bias of layer 2, times SKP_SCALE (it enters the activation's first multiply-add)
-  const float *b3;   // [1][64 lanes][16 regs] bias of layer 3 in accumulator layout
+  const float *b2;   // [256] bias of layer 2, times SKP_SCALE (bf16: + W 1 of the r-fold); the kernels read a lane's eight rows once per
+                     // launch and feed them to the matrix pipe as a 17th k-step (bf16 pairs against ones: skyjo_policy.hip)
+  const float *b3;   // [1][64 lanes][16 regs] bias of layer 3 in accumulator layout (read the same way: row (r & 3) + 8 (r >> 2) + 4 h)
   int out_dim;
   // float32-grade mode (SKYJO_MLP_FP32): every weight is the sum of two bf16 values, w = hi + lo; w1 / w2 / w3 above hold
   // the high halves, these the low halves in the same fragment layout
